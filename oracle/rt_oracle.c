@@ -1,0 +1,597 @@
+/* TEST INFRASTRUCTURE — not part of the product.  See rt_oracle.h.
+ *
+ * Plain-C restatement of the reference's hot path in IEEE double, in the
+ * reference's own operation order (Vec3 operators: Render2/vec3.h).  Build with
+ * -ffp-contract=off.  Parity status: PINNED against the compiled reference by
+ * tests/test_oracle_golden.py (vectors from oracle/gen_golden.py).
+ */
+#include "rt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- vec3.h restated ------------------------------------------------------ */
+typedef struct { double x, y, z; } v3;
+static inline v3 ld3(const double *p) { v3 a = {p[0], p[1], p[2]}; return a; }
+static inline void st3(double *p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+static inline v3 add(v3 a, v3 b) { v3 r = {a.x + b.x, a.y + b.y, a.z + b.z}; return r; }          /* vec3.h:22 */
+static inline v3 sub(v3 a, v3 b) { v3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }          /* vec3.h:26 */
+static inline v3 scl(double s, v3 a) { v3 r = {s * a.x, s * a.y, s * a.z}; return r; }            /* vec3.h:34,38 */
+static inline double dot(v3 a, v3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }          /* vec3.h:42 */
+static inline v3 divs(v3 a, double c) { v3 r = {a.x / c, a.y / c, a.z / c}; return r; }           /* vec3.h:46 */
+static inline v3 cross(v3 a, v3 b) {                                                              /* vec3.h:50 */
+	v3 r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+	return r;
+}
+static inline double len2(v3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }                      /* vec3.h:14 */
+static inline double len(v3 a) { return sqrt(len2(a)); }                                          /* vec3.h:18 */
+static inline v3 unit(v3 a) {                                                                     /* vec3.h:98 */
+	double d = len2(a);
+	v3 z = {0, 0, 0};
+	return d > 0.0 ? divs(a, sqrt(d)) : z;
+}
+static inline v3 remove_parallel(v3 a, v3 b) {                                                    /* vec3.h:70-75 */
+	double x = len2(b);
+	if (x > 0.0) return sub(a, scl(dot(a, b) / x, b));
+	return a;
+}
+
+/* ---- object.cpp:29-60 ------------------------------------------------------ */
+static inline double mt(v3 orig, v3 dir, v3 v0, v3 v1, v3 v2, double *u, double *v) {
+	v3 e1 = sub(v1, v0);
+	v3 e2 = sub(v2, v0);
+	v3 pvec = cross(dir, e2);
+	double det = dot(e1, pvec);
+	if (det < 1e-8 && det > -1e-8) return 0.0;
+	double inv_det = 1.0 / det;
+	v3 tvec = sub(orig, v0);
+	*u = dot(tvec, pvec) * inv_det;
+	if (*u < 0.0 || *u > 1.0) return 0.0;
+	v3 qvec = cross(tvec, e1);
+	*v = dot(dir, qvec) * inv_det;
+	if (*v < 0.0 || *u + *v > 1.0) return 0.0;
+	return dot(e2, qvec) * inv_det;
+}
+
+double rto_mt(const double o[3], const double d[3], const double v0[3], const double v1[3], const double v2[3],
+              double *u, double *v) {
+	return mt(ld3(o), ld3(d), ld3(v0), ld3(v1), ld3(v2), u, v);
+}
+
+void rto_mt_batch(long n, const double *o, const double *d, const double *v0, const double *v1, const double *v2,
+                  double *t, double *u, double *v) {
+	for (long i = 0; i < n; ++i) {
+		double uu = 0.0, vv = 0.0;
+		t[i] = mt(ld3(o + 3 * i), ld3(d + 3 * i), ld3(v0 + 3 * i), ld3(v1 + 3 * i), ld3(v2 + 3 * i), &uu, &vv);
+		u[i] = uu;
+		v[i] = vv;
+	}
+}
+
+/* object.cpp:143-168 semantics: keep strict minimum of positive t, first wins */
+static inline int32_t closest(long n_tris, const double *tris, v3 O, v3 D, double tmax, double *bt, double *bu,
+                              double *bv) {
+	double best = tmax, u0 = 0, v0 = 0;
+	int32_t bi = -1;
+	for (long i = 0; i < n_tris; ++i) {
+		const double *p = tris + 9 * i;
+		double uu = 0, vv = 0;
+		double t = mt(O, D, ld3(p), ld3(p + 3), ld3(p + 6), &uu, &vv);
+		if (t > 0.0 && best > t) { best = t; bi = (int32_t)i; u0 = uu; v0 = vv; }
+	}
+	*bt = bi >= 0 ? best : 0.0;
+	*bu = u0;
+	*bv = v0;
+	return bi;
+}
+
+void rto_closest_hit(long n_tris, const double *tris, long n_rays, const double *o, const double *d,
+                     const double *tmax, int32_t *tri, double *t, double *u, double *v) {
+#pragma omp parallel for schedule(dynamic, 64)
+	for (long k = 0; k < n_rays; ++k)
+		tri[k] = closest(n_tris, tris, ld3(o + 3 * k), ld3(d + 3 * k), tmax ? tmax[k] : RTO_INFINITY, &t[k], &u[k],
+		                 &v[k]);
+}
+
+void rto_any_hit(long n_tris, const double *tris, long n_rays, const double *o, const double *d, const double *tmax,
+                 uint8_t *occluded) {
+#pragma omp parallel for schedule(dynamic, 64)
+	for (long k = 0; k < n_rays; ++k) {
+		v3 O = ld3(o + 3 * k), D = ld3(d + 3 * k);
+		double lim = tmax ? tmax[k] : RTO_INFINITY;
+		uint8_t occ = 0;
+		for (long i = 0; i < n_tris && !occ; ++i) {
+			const double *p = tris + 9 * i;
+			double uu = 0, vv = 0;
+			double tt = mt(O, D, ld3(p), ld3(p + 3), ld3(p + 6), &uu, &vv);
+			if (tt > 0.0 && tt < lim) occ = 1;
+		}
+		occluded[k] = occ;
+	}
+}
+
+/* ---- rasterizer.cpp:40-56, 230 --------------------------------------------- */
+void rto_raster_details(const double *c, uint32_t x_res, uint32_t y_res, double *out18) {
+	v3 eye = ld3(c), lookat = ld3(c + 3), up = ld3(c + 6);
+	double vpdist = c[9], xmin = c[10], ymax = c[13];
+	double width = c[11] - c[10];  /* interval.h:15-20 Len() */
+	if (!(width > 0.0)) width = 0.0;
+	double height = c[13] - c[12];
+	if (!(height > 0.0)) height = 0.0;
+	v3 G = unit(sub(lookat, eye));
+	v3 U = unit(remove_parallel(up, G));
+	v3 R = unit(cross(G, U));
+	v3 O = add(add(scl(vpdist, G), scl(xmin, R)), scl(ymax, U));
+	v3 dR = divs(scl(width, R), (double)x_res);
+	v3 dU = divs(scl(height, U), (double)y_res);
+	st3(out18, G); st3(out18 + 3, U); st3(out18 + 6, R); st3(out18 + 9, O); st3(out18 + 12, dR); st3(out18 + 15, dU);
+}
+
+void rto_primary_dirs(const double *rd, long n, const uint32_t *pix, double *dir) {
+	v3 O = ld3(rd + 9), dR = ld3(rd + 12), dU = ld3(rd + 15);
+	for (long k = 0; k < n; ++k) {
+		uint32_t i = pix[2 * k], j = pix[2 * k + 1];
+		st3(dir + 3 * k, unit(sub(add(O, scl(j + 0.5, dR)), scl(i + 0.5, dU))));
+	}
+}
+
+/* object.cpp:23 */
+static inline v3 hit_point(v3 o, v3 d, v3 v1, v3 n) {
+	return add(o, divs(scl(dot(sub(v1, o), n), d), dot(n, d)));
+}
+void rto_hit_point(const double o[3], const double d[3], const double v1[3], const double nrm[3], double p[3]) {
+	st3(p, hit_point(ld3(o), ld3(d), ld3(v1), ld3(nrm)));
+}
+
+void rto_shadow_rays(long n, const double *P, const double *N, const double C[3], double *o, double *d) {
+	v3 c = ld3(C);
+	for (long k = 0; k < n; ++k) {
+		v3 p = ld3(P + 3 * k), nn = ld3(N + 3 * k);
+		st3(d + 3 * k, unit(sub(c, p)));
+		st3(o + 3 * k, add(p, scl(0.01, nn)));
+	}
+}
+
+/* ---- radiosity -------------------------------------------------------------- */
+double rto_area(const double a[3], const double b[3], const double c[3]) {
+	return len(cross(sub(ld3(b), ld3(a)), sub(ld3(c), ld3(a)))) / 2.0;
+}
+
+/* radiosity.cpp:231-262 */
+static int visible(long n, const double *verts, const double *normals, int32_t j, v3 xi, v3 yi) {
+	v3 dir = unit(sub(yi, xi));
+	v3 org = add(xi, scl(RTO_EPSILON, dir));
+	double t, u, v;
+	int32_t h = closest(n, verts, org, dir, RTO_INFINITY, &t, &u, &v);
+	if (h < 0) return 0;
+	v3 p = hit_point(org, dir, ld3(verts + 9 * h), ld3(normals + 3 * h));
+	return (len(sub(p, yi)) < RTO_EPSILON && dot(dir, ld3(normals + 3 * j)) < 0) ? 1 : 0;
+}
+
+void rto_visible(long n, const double *verts, const double *normals, long m, const int32_t *ei, const int32_t *ej,
+                 const double *xi, const double *xj, uint8_t *vis) {
+	(void)ei;
+#pragma omp parallel for schedule(dynamic, 16)
+	for (long k = 0; k < m; ++k) vis[k] = (uint8_t)visible(n, verts, normals, ej[k], ld3(xi + 3 * k), ld3(xj + 3 * k));
+}
+
+static int light_blocked(long n, const double *verts, v3 ni, v3 x, v3 C) {
+	v3 dir = unit(sub(C, x));
+	v3 org = add(x, scl(RTO_EPSILON, ni));
+	double t, u, v;
+	return closest(n, verts, org, dir, RTO_INFINITY, &t, &u, &v) >= 0;
+}
+
+void rto_light_blocked(long n, const double *verts, const double *normals, long m, const int32_t *ei,
+                       const double *xi, const double C[3], uint8_t *blocked) {
+#pragma omp parallel for schedule(dynamic, 16)
+	for (long k = 0; k < m; ++k)
+		blocked[k] = (uint8_t)light_blocked(n, verts, ld3(normals + 3 * ei[k]), ld3(xi + 3 * k), ld3(C));
+}
+
+/* splitmix64 finaliser chained over the stream coordinates */
+static inline uint64_t mix64(uint64_t z) {
+	z += 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+uint64_t rto_hash(uint64_t seed, uint32_t a, uint32_t b, uint32_t k, uint32_t which) {
+	uint64_t h = mix64(seed ^ (((uint64_t)a << 32) | b));
+	return mix64(h ^ (((uint64_t)k << 32) | which));
+}
+
+void rto_sample_point(const double *e, uint64_t seed, uint32_t a, uint32_t b, uint32_t k, uint32_t which,
+                      double p[3]) {
+	uint64_t h = rto_hash(seed, a, b, k, which);
+	double u = (double)(h >> 11) * 0x1.0p-53;
+	double v = (double)(mix64(h) >> 11) * 0x1.0p-53;
+	if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
+	double w = 1.0 - u - v;
+	for (int c = 0; c < 3; ++c) p[c] = (w * e[c]) + (u * e[3 + c]) + (v * e[6 + c]); /* util.cpp:113-115 */
+}
+
+/* radiosity.cpp:305-333 */
+static double ff_term(long n, const double *verts, const double *normals, int32_t i, int32_t j, uint32_t S,
+                      const double *xi, const double *xj) {
+	double ff = 0;
+	v3 ni = ld3(normals + 3 * i), nj = ld3(normals + 3 * j);
+	double area_j = rto_area(verts + 9 * j, verts + 9 * j + 3, verts + 9 * j + 6);
+	for (uint32_t k = 0; k < S; ++k) {
+		v3 a = ld3(xi + 3 * k), b = ld3(xj + 3 * k);
+		if (visible(n, verts, normals, j, a, b)) {
+			v3 ab = sub(a, b);
+			double dist2 = dot(ab, ab);
+			double c1 = dot(unit(sub(b, a)), ni);
+			double c2 = dot(unit(sub(a, b)), nj);
+			double cosFactor = c1 * c2;
+			double delF = (c1 < 0.0 || c2 < 0.0) ? 0.0 : cosFactor / ((RTO_PI * dist2) + (area_j / (int)S));
+			if (delF > 0.0) ff += delF;
+		}
+	}
+	ff = ff / ((double)S);
+	return ff * area_j;
+}
+
+double rto_ff_term_points(long n, const double *verts, const double *normals, int32_t i, int32_t j, uint32_t S,
+                          const double *xi, const double *xj) {
+	return ff_term(n, verts, normals, i, j, S, xi, xj);
+}
+
+void rto_form_factors(long n, const double *verts, const double *normals, uint32_t S, uint64_t seed, long row0,
+                      long n_rows, long ld, double *F) {
+#pragma omp parallel for schedule(dynamic, 1)
+	for (long r = 0; r < n_rows; ++r) {
+		long i = row0 + r;
+		double *xi = (double *)malloc(sizeof(double) * 6 * S), *xj = xi + 3 * S;
+		for (long j = 0; j < n; ++j) {
+			if (i == j) { F[r * ld + j] = 0.0; continue; }
+			for (uint32_t k = 0; k < S; ++k) {
+				rto_sample_point(verts + 9 * i, seed, (uint32_t)i, (uint32_t)j, k, 0, xi + 3 * k);
+				rto_sample_point(verts + 9 * j, seed, (uint32_t)i, (uint32_t)j, k, 1, xj + 3 * k);
+			}
+			F[r * ld + j] = ff_term(n, verts, normals, (int32_t)i, (int32_t)j, S, xi, xj);
+		}
+		free(xi);
+	}
+}
+
+/* radiosity.cpp:264-303 */
+static double light_term(long n, const double *verts, const double *normals, v3 C, int32_t i, uint32_t S,
+                         const double *xi, int mirror_bug) {
+	double ff = 0.0;
+	v3 ni = ld3(normals + 3 * i);
+	for (uint32_t k = 0; k < S; ++k) {
+		if (mirror_bug) ff = 0.0; /* :276 */
+		v3 x = ld3(xi + 3 * k);
+		if (!light_blocked(n, verts, ni, x, C)) {
+			v3 dir = unit(sub(C, x));
+			double L = len(sub(C, x));
+			double tmp = ((1.0 / (4.0 * RTO_PI)) * (dot(dir, ni) / (L * L)));
+			if (tmp > 0.0) ff += tmp;
+		}
+	}
+	return ff / ((double)S);
+}
+
+double rto_light_term_points(long n, const double *verts, const double *normals, const double C[3], int32_t i,
+                             uint32_t S, const double *xi, int mirror_bug) {
+	return light_term(n, verts, normals, ld3(C), i, S, xi, mirror_bug);
+}
+
+void rto_light_terms(long n, const double *verts, const double *normals, const double C[3], uint32_t S,
+                     uint64_t seed, int mirror_bug, long row0, long n_rows, double *f) {
+#pragma omp parallel for schedule(dynamic, 4)
+	for (long r = 0; r < n_rows; ++r) {
+		long i = row0 + r;
+		double *xi = (double *)malloc(sizeof(double) * 3 * S);
+		for (uint32_t k = 0; k < S; ++k)
+			rto_sample_point(verts + 9 * i, seed, (uint32_t)i, 0xFFFFFFFFu, k, 0, xi + 3 * k);
+		f[r] = light_term(n, verts, normals, ld3(C), (int32_t)i, S, xi, mirror_bug);
+		free(xi);
+	}
+}
+
+/* radiosity.cpp:469-481 on K = I − ρF (element rows), light row = identity (:413-428) */
+static int converged(long n, const double *F, double rho, const double *B, const double *E) {
+	for (long i = 0; i < n; ++i) {
+		double sum = 0.0;
+		for (long j = 0; j < n; ++j) {
+			double I = (i == j) ? 1.0 : 0.0;
+			double Kij = (i < n - 1) ? I - (rho * F[i * n + j]) : I - F[i * n + j];
+			sum += Kij * B[j];
+		}
+		if (fabs(sum - E[i]) > RTO_EPSILON) return 0;
+	}
+	return 1;
+}
+
+long rto_progressive_refinement(long n, const double *F, const double *area, double rho, double power,
+                                long max_shots, double *B) {
+	double *E = (double *)calloc((size_t)n, sizeof(double));
+	double *dB = (double *)malloc(sizeof(double) * (size_t)n);
+	double *tmp = (double *)calloc((size_t)n, sizeof(double)); /* [n-1] stays 0: see header */
+	E[n - 1] = power;
+	for (long i = 0; i < n; ++i) { dB[i] = E[i]; B[i] = E[i]; }
+	int first = 1;
+	long shots = 0;
+	while (!converged(n, F, rho, B, E)) {
+		if (shots >= max_shots) { shots = -1; break; }
+		long indx;
+		if (first) {
+			first = 0;
+			for (long i = 0; i < n - 1; ++i) {
+				double dRad = dB[n - 1] * F[i * n + (n - 1)] * rho;
+				dB[i] += dRad;
+				B[i] += dRad;
+			}
+			indx = n - 1;
+		} else {
+			for (long i = 0; i < n - 1; ++i) tmp[i] = dB[i] * area[i];
+			double val = 0.0; /* util.cpp:84-94 */
+			indx = 0;
+			for (long i = 0; i < n; ++i)
+				if (val < tmp[i]) { val = tmp[i]; indx = i; }
+			for (long i = 0; i < n; ++i) {
+				double dRad = dB[indx] * F[i * n + indx] * rho;
+				dB[i] += dRad;
+				B[i] += dRad;
+			}
+		}
+		dB[indx] = 0.0;
+		++shots;
+	}
+	free(E); free(dB); free(tmp);
+	return shots;
+}
+
+int rto_direct_solve(long n, const double *F, double rho, double power, double *B) {
+	double *A = (double *)malloc(sizeof(double) * (size_t)n * (size_t)(n + 1));
+	long w = n + 1;
+	for (long i = 0; i < n; ++i) {
+		for (long j = 0; j < n; ++j) {
+			double I = (i == j) ? 1.0 : 0.0;
+			A[i * w + j] = (i < n - 1) ? I - rho * F[i * n + j] : I - F[i * n + j];
+		}
+		A[i * w + n] = (i == n - 1) ? power : 0.0;
+	}
+	for (long c = 0; c < n; ++c) {
+		long piv = c;
+		for (long r = c + 1; r < n; ++r)
+			if (fabs(A[r * w + c]) > fabs(A[piv * w + c])) piv = r;
+		if (A[piv * w + c] == 0.0) { free(A); return 1; }
+		if (piv != c)
+			for (long j = 0; j <= n; ++j) { double t = A[c * w + j]; A[c * w + j] = A[piv * w + j]; A[piv * w + j] = t; }
+		for (long r = c + 1; r < n; ++r) {
+			double f = A[r * w + c] / A[c * w + c];
+			if (f == 0.0) continue;
+			for (long j = c; j <= n; ++j) A[r * w + j] -= f * A[c * w + j];
+		}
+	}
+	for (long i = n - 1; i >= 0; --i) {
+		double s = A[i * w + n];
+		for (long j = i + 1; j < n; ++j) s -= A[i * w + j] * B[j];
+		B[i] = s / A[i * w + i];
+	}
+	free(A);
+	return 0;
+}
+
+long rto_jacobi_rgb(long n, const float *F, const double rho[3], const double *E, double tol_rel, long max_sweeps,
+                    double *B) {
+	double *Bn = (double *)malloc(sizeof(double) * 3 * (size_t)n);
+	memcpy(B, E, sizeof(double) * 3 * (size_t)n);
+	long s = 0;
+	for (; s < max_sweeps; ++s) {
+		double d2 = 0, b2 = 0;
+#pragma omp parallel for reduction(+ : d2, b2) schedule(static)
+		for (long i = 0; i < n; ++i) {
+			double a0 = 0, a1 = 0, a2 = 0;
+			const float *row = F + (size_t)i * (size_t)n;
+			for (long j = 0; j < n; ++j) {
+				double f = (double)row[j];
+				a0 += f * B[3 * j]; a1 += f * B[3 * j + 1]; a2 += f * B[3 * j + 2];
+			}
+			double r[3] = {E[3 * i] + rho[0] * a0, E[3 * i + 1] + rho[1] * a1, E[3 * i + 2] + rho[2] * a2};
+			for (int c = 0; c < 3; ++c) {
+				double dd = r[c] - B[3 * i + c];
+				d2 += dd * dd;
+				b2 += r[c] * r[c];
+				Bn[3 * i + c] = r[c];
+			}
+		}
+		memcpy(B, Bn, sizeof(double) * 3 * (size_t)n);
+		if (sqrt(d2) <= tol_rel * sqrt(b2)) { ++s; break; }
+	}
+	free(Bn);
+	return s;
+}
+
+/* ---- CPU baseline BVH (ours; the reference's own accelerator is a BSP that cannot build
+ * the large synthetic scenes) ------------------------------------------ */
+typedef struct { double lo[3], hi[3]; int32_t left, right, first, count; } bnode;
+struct rto_bvh { long n_tris, n_nodes; bnode *nodes; int32_t *order; const double *tris; double *tcopy; };
+
+typedef struct { double lo[3], hi[3], c[3]; } tbox;
+
+static void box_of(const double *p, tbox *b) {
+	for (int a = 0; a < 3; ++a) {
+		double x = p[a], y = p[3 + a], z = p[6 + a];
+		double lo = x < y ? x : y; lo = lo < z ? lo : z;
+		double hi = x > y ? x : y; hi = hi > z ? hi : z;
+		b->lo[a] = lo; b->hi[a] = hi; b->c[a] = 0.5 * (lo + hi);
+	}
+}
+static double half_area(const double lo[3], const double hi[3]) {
+	double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+	return dx * dy + dy * dz + dz * dx;
+}
+
+static int32_t build_rec(rto_bvh *b, const tbox *tb, int32_t first, int32_t count, int depth) {
+	int32_t id = (int32_t)b->n_nodes++;
+	bnode *nd = &b->nodes[id];
+	double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+	for (int a = 0; a < 3; ++a) { nd->lo[a] = 1e300; nd->hi[a] = -1e300; }
+	for (int32_t i = first; i < first + count; ++i) {
+		const tbox *t = &tb[b->order[i]];
+		for (int a = 0; a < 3; ++a) {
+			if (t->lo[a] < nd->lo[a]) nd->lo[a] = t->lo[a];
+			if (t->hi[a] > nd->hi[a]) nd->hi[a] = t->hi[a];
+			if (t->c[a] < clo[a]) clo[a] = t->c[a];
+			if (t->c[a] > chi[a]) chi[a] = t->c[a];
+		}
+	}
+	nd->left = nd->right = -1; nd->first = first; nd->count = count;
+	if (count <= 4 || depth > 60) return id;
+	enum { NB = 16 };
+	int best_axis = -1, best_split = 0;
+	double best_cost = 1e300;
+	for (int a = 0; a < 3; ++a) {
+		double ext = chi[a] - clo[a];
+		if (!(ext > 0)) continue;
+		int cnt[NB] = {0};
+		double blo[NB][3], bhi[NB][3];
+		for (int k = 0; k < NB; ++k)
+			for (int c = 0; c < 3; ++c) { blo[k][c] = 1e300; bhi[k][c] = -1e300; }
+		for (int32_t i = first; i < first + count; ++i) {
+			const tbox *t = &tb[b->order[i]];
+			int k = (int)(NB * ((t->c[a] - clo[a]) / ext));
+			if (k >= NB) k = NB - 1;
+			cnt[k]++;
+			for (int c = 0; c < 3; ++c) {
+				if (t->lo[c] < blo[k][c]) blo[k][c] = t->lo[c];
+				if (t->hi[c] > bhi[k][c]) bhi[k][c] = t->hi[c];
+			}
+		}
+		double ra[NB]; int rc[NB];
+		double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+		int c2 = 0;
+		for (int k = NB - 1; k > 0; --k) {
+			for (int c = 0; c < 3; ++c) { if (blo[k][c] < lo[c]) lo[c] = blo[k][c]; if (bhi[k][c] > hi[c]) hi[c] = bhi[k][c]; }
+			c2 += cnt[k];
+			ra[k] = c2 ? half_area(lo, hi) : 0; rc[k] = c2;
+		}
+		for (int c = 0; c < 3; ++c) { lo[c] = 1e300; hi[c] = -1e300; }
+		int c1 = 0;
+		for (int k = 0; k < NB - 1; ++k) {
+			for (int c = 0; c < 3; ++c) { if (blo[k][c] < lo[c]) lo[c] = blo[k][c]; if (bhi[k][c] > hi[c]) hi[c] = bhi[k][c]; }
+			c1 += cnt[k];
+			if (c1 == 0 || rc[k + 1] == 0) continue;
+			double cost = half_area(lo, hi) * c1 + ra[k + 1] * rc[k + 1];
+			if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
+		}
+	}
+	int32_t mid;
+	if (best_axis < 0) {
+		mid = first + count / 2;
+	} else {
+		double ext = chi[best_axis] - clo[best_axis];
+		int32_t i = first, j = first + count - 1;
+		while (i <= j) {
+			const tbox *t = &tb[b->order[i]];
+			int k = (int)(NB * ((t->c[best_axis] - clo[best_axis]) / ext));
+			if (k >= NB) k = NB - 1;
+			if (k <= best_split) ++i;
+			else { int32_t s = b->order[i]; b->order[i] = b->order[j]; b->order[j] = s; --j; }
+		}
+		mid = i;
+		if (mid == first || mid == first + count) mid = first + count / 2;
+	}
+	int32_t l = build_rec(b, tb, first, mid - first, depth + 1);
+	int32_t r = build_rec(b, tb, mid, first + count - mid, depth + 1);
+	b->nodes[id].left = l; b->nodes[id].right = r;
+	return id;
+}
+
+rto_bvh *rto_bvh_build(long n, const double *tris) {
+	rto_bvh *b = (rto_bvh *)calloc(1, sizeof(rto_bvh));
+	b->n_tris = n;
+	b->tcopy = (double *)malloc(sizeof(double) * 9 * (size_t)n);
+	memcpy(b->tcopy, tris, sizeof(double) * 9 * (size_t)n);
+	b->tris = b->tcopy;
+	b->nodes = (bnode *)malloc(sizeof(bnode) * (size_t)(2 * n + 1));
+	b->order = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+	tbox *tb = (tbox *)malloc(sizeof(tbox) * (size_t)n);
+	for (long i = 0; i < n; ++i) { b->order[i] = (int32_t)i; box_of(tris + 9 * i, &tb[i]); }
+	if (n > 0) build_rec(b, tb, 0, (int32_t)n, 0);
+	free(tb);
+	return b;
+}
+
+void rto_bvh_free(rto_bvh *b) {
+	if (!b) return;
+	free(b->nodes); free(b->order); free(b->tcopy); free(b);
+}
+
+/* slab test in double, widened by a relative 1e-9 so the exact test decides */
+static inline int box_hit(const bnode *n, v3 o, v3 inv, double tbest, double *tn) {
+	double pad = 1e-9 * (fabs(o.x) + fabs(o.y) + fabs(o.z) + fabs(n->hi[0]) + fabs(n->lo[0]) + fabs(n->hi[1]) +
+	                     fabs(n->lo[1]) + fabs(n->hi[2]) + fabs(n->lo[2]) + 1.0);
+	double t0 = 0, t1 = tbest * (1 + 1e-9) + 1e-12;
+	const double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+	for (int a = 0; a < 3; ++a) {
+		double ta = (n->lo[a] - pad - oo[a]) * ii[a], tb = (n->hi[a] + pad - oo[a]) * ii[a];
+		if (isnan(ta) || isnan(tb)) continue; /* 0 * inf: origin on a padded plane of a parallel slab */
+		if (ta > tb) { double s = ta; ta = tb; tb = s; }
+		if (ta > t0) t0 = ta;
+		if (tb < t1) t1 = tb;
+	}
+	*tn = t0;
+	return t0 <= t1;
+}
+
+double rto_bvh_closest_hit(const rto_bvh *b, long n_rays, const double *o, const double *d, const double *tmax,
+                           int32_t *tri, double *t, double *u, double *v) {
+	struct timespec a, z;
+	clock_gettime(CLOCK_MONOTONIC, &a);
+#pragma omp parallel for schedule(dynamic, 256)
+	for (long k = 0; k < n_rays; ++k) {
+		v3 O = ld3(o + 3 * k), D = ld3(d + 3 * k);
+		v3 inv = {1.0 / D.x, 1.0 / D.y, 1.0 / D.z};
+		double best = tmax ? tmax[k] : RTO_INFINITY, bu = 0, bv = 0;
+		int32_t bi = -1;
+		int32_t stack[128];
+		int sp = 0;
+		if (b->n_tris > 0) stack[sp++] = 0;
+		while (sp) {
+			const bnode *n = &b->nodes[stack[--sp]];
+			double tn;
+			if (!box_hit(n, O, inv, best, &tn)) continue;
+			if (n->left < 0) {
+				for (int32_t i = n->first; i < n->first + n->count; ++i) {
+					int32_t id = b->order[i];
+					const double *p = b->tris + 9 * (long)id;
+					double uu = 0, vv = 0;
+					double tt = mt(O, D, ld3(p), ld3(p + 3), ld3(p + 6), &uu, &vv);
+					/* same winner as the in-order scan: smaller t, or equal t and smaller index */
+					if (tt > 0.0 && (best > tt || (bi >= 0 && best == tt && id < bi))) { best = tt; bi = id; bu = uu; bv = vv; }
+				}
+			} else {
+				double t0, t1;
+				int h0 = box_hit(&b->nodes[n->left], O, inv, best, &t0);
+				int h1 = box_hit(&b->nodes[n->right], O, inv, best, &t1);
+				if (h0 && h1) {
+					if (t0 <= t1) { stack[sp++] = n->right; stack[sp++] = n->left; }
+					else { stack[sp++] = n->left; stack[sp++] = n->right; }
+				} else if (h0) stack[sp++] = n->left;
+				else if (h1) stack[sp++] = n->right;
+			}
+		}
+		tri[k] = bi; t[k] = bi >= 0 ? best : 0.0; u[k] = bu; v[k] = bv;
+	}
+	clock_gettime(CLOCK_MONOTONIC, &z);
+	return (double)(z.tv_sec - a.tv_sec) + 1e-9 * (double)(z.tv_nsec - a.tv_nsec);
+}
+
+int rto_num_threads(void) {
+#ifdef _OPENMP
+	return omp_get_max_threads();
+#else
+	return 1;
+#endif
+}
