@@ -1,0 +1,174 @@
+/* rtmi.h — C ABI of librtmi.so: MI355X (gfx950) ray queries and radiosity for the
+ * AryaGosuDev/RayTracer host driver.
+ *
+ * The reference has no FFI for this path; its seams are C++ members.  Each entry
+ * point below names the reference interface it replaces (paths relative to the reference repo).
+ * The host side (scene reader, OBJ loader, shader, PPM writer) stays the reference's own code and
+ * calls these with *batches*: one call per wavefront of rays, not one call per ray.
+ *
+ * Conventions
+ *   - plain C, opaque handles, int status: 0 = OK, negative = error; text via rtmi_last_error()
+ *     (thread-local).  No exception crosses the boundary.
+ *   - all geometry and rays are IEEE double, as in the reference (Render2/vec3.h:6-12).  The kernels
+ *     evaluate the reference's Möller–Trumbore in double, in the reference's operation order, so hit
+ *     ids and t/u/v are bit-identical to brute force over the input triangles with
+ *     triangle_intersection (Render2/object.cpp:29-60).  Boxes are fp32 and conservatively padded.
+ *   - "_dev" entry points take device pointers (resident in HBM) and a hipStream_t passed as void*;
+ *     they are asynchronous on that stream.  The others take host pointers and are synchronous.
+ *   - a scene lives on ONE device (the current HIP device at rtmi_scene_create).  Multi-GPU = one
+ *     process (or one scene) per GPU; rays, image tiles and form-factor rows shard with no collective;
+ *     only the radiosity solve exchanges data (the caller all-gathers B between sweeps).
+ */
+#ifndef RTMI_H
+#define RTMI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_MISS 0xFFFFFFFFu
+#define RTMI_INFINITY 1.0e20 /* Render2/base.h:56 — "no tmax" */
+
+/* Render2/ray.h:23-32 (origin, unit direction); tmax <= 0 or >= 1e20 means 1e20. 64 bytes. */
+typedef struct rtmi_ray {
+	double o[3];
+	double d[3];
+	double tmax;
+	double reserved;
+} rtmi_ray;
+
+/* What Scene::Cast leaves in HitInfo (Render2/ray_tracer.h:83-111) that is reproducible:
+ * distance, barycentrics (float there too), the ORIGINAL triangle's flattened index and its
+ * object.  tri == RTMI_MISS on a miss (then t = 0).  24 bytes. */
+typedef struct rtmi_hit {
+	double t;
+	float u, v;
+	uint32_t tri;
+	uint32_t object;
+} rtmi_hit;
+
+/* Render2/rasterizer.cpp:11-68 (RasterDetails) as the kernels need it.  Filled by rtmi_camera_setup. */
+typedef struct rtmi_camera {
+	double eye[3];
+	double O[3], dR[3], dU[3];
+	uint32_t x_res, y_res;
+} rtmi_camera;
+
+typedef struct rtmi_scene rtmi_scene;
+
+typedef struct rtmi_scene_info {
+	uint64_t n_tris, n_nodes, n_leaves;
+	uint32_t max_depth, max_leaf_size;
+	double build_seconds;
+	uint64_t device_bytes;
+	float scene_lo[3], scene_hi[3];
+} rtmi_scene_info;
+
+const char *rtmi_last_error(void);
+int rtmi_device_count(void);
+
+/* ---- acceleration structure -------------------------------------------------------------------
+ * Replaces Scene::BuildBSP (Render2/scene.cpp:463-479, 528-693).  tri_xyz: n_tris × 9 doubles
+ * (triVert1, triVert2, triVert3) in Scene::sceneObjects / Object::triangles order — that order IS
+ * the triangle id.  tri_object (may be NULL = all 0): index into sceneObjects.  Builds a binned-SAH
+ * BVH on the host, flattens it, uploads to the current device. */
+rtmi_scene *rtmi_scene_create(const double *tri_xyz, const uint32_t *tri_object, uint64_t n_tris);
+void rtmi_scene_destroy(rtmi_scene *);
+int rtmi_scene_get_info(const rtmi_scene *, rtmi_scene_info *out);
+
+/* ---- closest hit --------------------------------------------------------------------------------
+ * Replaces bool Scene::Cast(const Ray&, HitInfo&) (Render2/scene.cpp:159-207) and
+ * Object::Intersect (Render2/object.cpp:170-184): strict minimum of the positive t below tmax;
+ * equal t -> smallest triangle id. */
+int rtmi_closest_hit(rtmi_scene *, const rtmi_ray *rays, uint64_t n, rtmi_hit *out);
+int rtmi_closest_hit_dev(rtmi_scene *, const rtmi_ray *d_rays, uint64_t n, rtmi_hit *d_out, void *stream);
+
+/* ---- primary rays generated on the device --------------------------------------------------------
+ * rtmi_camera_setup replaces the RasterDetails constructor (Render2/rasterizer.cpp:40-56).
+ * rtmi_primary_closest_hit_dev replaces the ray loop of Serial_Normal_Raster
+ * (Render2/rasterizer.cpp:219-233): ray(i,j) = eye -> Unit(O + (j+sx)·dR − (i+sy)·dU), sx = sy = 0.5
+ * in the reference.  The image is cut into tile_w × tile_h tiles numbered row-major; this call traces
+ * tiles tile_first, tile_first + tile_stride, ... (tile_stride = number of GPUs) and writes
+ * d_out[i·x_res + j] of a full x_res·y_res frame; other pixels are left untouched.
+ * rtmi_primary_rays_dev writes the same rays out instead of tracing them (all pixels). */
+int rtmi_camera_setup(const double eye[3], const double lookat[3], const double up[3], double vpdist,
+                      const double x_win[2], const double y_win[2], uint32_t x_res, uint32_t y_res,
+                      rtmi_camera *out);
+int rtmi_primary_closest_hit_dev(rtmi_scene *, const rtmi_camera *cam, double sx, double sy, uint32_t tile_w,
+                                 uint32_t tile_h, uint32_t tile_first, uint32_t tile_stride, rtmi_hit *d_out,
+                                 void *stream);
+int rtmi_primary_rays_dev(const rtmi_camera *cam, double sx, double sy, rtmi_ray *d_rays, void *stream);
+
+/* ---- any hit --------------------------------------------------------------------------------------
+ * Replaces Scene::Cast used as a predicate: shadows (Render2/shader.cpp:131, tmax = 1e20), ambient
+ * occlusion (Render2/shader.cpp:226, tmax = radius), light visibility (Render2/radiosity.cpp:290).
+ * occluded[k] = 1 iff some triangle has 0 < t < tmax. */
+int rtmi_any_hit(rtmi_scene *, const rtmi_ray *rays, uint64_t n, uint8_t *occluded);
+int rtmi_any_hit_dev(rtmi_scene *, const rtmi_ray *d_rays, uint64_t n, uint8_t *d_occluded, void *stream);
+
+/* ---- radiosity: form factors ------------------------------------------------------------------------
+ * The patches are the scene's triangles (elements = the leaves every visibility ray is tested
+ * against, Render2/radiosity.cpp:137-163), so patch i = triangle i of the scene.  verts: n × 9 doubles,
+ * normals: n × 3 doubles = the reference's triNormal per element (host pointers, copied). */
+typedef struct rtmi_patches rtmi_patches;
+rtmi_patches *rtmi_patches_create(rtmi_scene *, const double *verts /* the array the scene was built from */,
+                                  const double *normals);
+void rtmi_patches_destroy(rtmi_patches *);
+
+/* Replaces bool Radiosity::isVisibleXiToXj (Render2/radiosity.cpp:231-262) on m injected point pairs
+ * (host pointers): vis[k] = closest hit from xi+1e-5·d lands within 1e-5 of xj  and  d·n_ej < 0. */
+int rtmi_visible_points(rtmi_patches *, uint64_t m, const int32_t *ej, const double *xi, const double *xj,
+                        uint8_t *vis);
+
+#define RTMI_FF_LIGHT_MEAN 1u /* average all light samples instead of mirroring Render2/radiosity.cpp:276 */
+
+/* Replaces Radiosity::findFormFactor's two fill loops (Render2/radiosity.cpp:379-403) with
+ * findFormFactorTerm (:305-333) and findFormFactorTermWithLight (:264-303).  Sample points come from
+ * the counter-based generator documented in DESIGN.md (stream = seed, i, j, sample).
+ * n = n_patches + 1 (the light is patch n-1, its row is zero) if light_center != NULL, else n_patches.
+ * Writes rows [row0, row0+n_rows) of the n × n matrix as fp32: d_F[(r-row0)·ld + c].  Rows shard
+ * across GPUs with no communication. */
+int rtmi_form_factors_dev(rtmi_patches *, const double *light_center, uint32_t samples, uint32_t light_samples,
+                          uint64_t seed, uint32_t flags, uint32_t row0, uint32_t n_rows, float *d_F, uint64_t ld,
+                          void *stream);
+
+/* ---- radiosity: solve ----------------------------------------------------------------------------------
+ * Replaces Radiosity::progressiveRefinement + checkIfConverged (Render2/radiosity.cpp:483-563,
+ * 469-481): both iterate to the solution of (I − ρF)·B = E; here by Jacobi sweeps
+ *     B_new[i][c] = E[i][c] + rho[c] · Σ_j F[i][j] · B_old[j][c]      c = R,G,B
+ * F fp32 (streamed from HBM once per sweep), B/E fp32 [n][3], accumulation in double.
+ * One call = one sweep over rows [row0, row0+n_rows): reads d_B_old (all n), writes
+ * d_B_new[row0..row0+n_rows) (same [n][3] indexing) and ADDS to d_norms[0] += Σ(B_new−B_old)²,
+ * d_norms[1] += ΣB_new², d_norms[2] = max(d_norms[2], max|B_new−B_old|) over its rows
+ * (the caller zeroes d_norms; [2] is the reference's stop quantity, :478).
+ * Multi-GPU: rows shard; the caller all-gathers d_B_new between sweeps (RCCL). */
+int rtmi_jacobi_sweep_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows,
+                          const double rho[3], const float *d_E, const float *d_B_old, float *d_B_new,
+                          double *d_norms, void *stream);
+
+typedef struct rtmi_solve_stats {
+	uint32_t sweeps;
+	double rel_change; /* ‖B_k − B_{k-1}‖₂ / ‖B_k‖₂ at exit */
+	double max_change; /* max_i |B_k − B_{k-1}| at exit = max residual of B_{k-1} */
+	double seconds;    /* device time of the sweeps (HIP events) */
+	double bytes_per_sweep;
+} rtmi_solve_stats;
+
+/* exchange hook: called after every sweep with the stream the sweep ran on; must make
+ * d_B (all n rows) hold every rank's rows and sum d_norms[0..1] / max d_norms[2] across ranks
+ * before returning (stream-ordered).  NULL = single GPU. */
+typedef int (*rtmi_exchange_fn)(void *user, float *d_B, double *d_norms, void *stream);
+
+/* Whole solve on device-resident F (rows [row0,row0+n_rows) local).  d_B [n][3] receives the
+ * result (every rank gets all rows when exchange != NULL).  Stops when rel_change <= tol_rel
+ * (checked every check_every sweeps) or after max_sweeps. */
+int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows,
+                             const double rho[3], const float *d_E, float *d_B, float tol_rel, uint32_t max_sweeps,
+                             uint32_t check_every, rtmi_exchange_fn exchange, void *user, rtmi_solve_stats *stats,
+                             void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

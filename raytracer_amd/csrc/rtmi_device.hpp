@@ -1,0 +1,204 @@
+// Device-side data layout and the traversal core shared by the ray-query and radiosity kernels.
+// gfx950 only.  Compile with -ffp-contract=off: the double-precision Möller–Trumbore below must
+// round exactly like the reference's scalar C++ (Render2/object.cpp:29-60); fused multiply-adds are
+// written out explicitly where they are wanted (fp32 box tests never need them).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtmi.h"
+
+namespace rtmi {
+
+// ---------------------------------------------------------------- HBM layout
+// BVH2 inner node, 64 B = half a 128-B L2 line; both children's fp32 boxes + their references.
+//   a = (lo0.x, hi0.x, lo0.y, hi0.y)   b = (lo1.x, hi1.x, lo1.y, hi1.y)
+//   c = (lo0.z, hi0.z, lo1.z, hi1.z)   d = (ref0, ref1, -, -)
+// ref >= 0: index of an inner node;  ref < 0: leaf, ~ref = (first << 3) | (count - 1), count <= 8,
+// first = index into the leaf-ordered triangle array.
+struct __attribute__((aligned(16))) GNode {
+	float4 a, b, c;
+	int4 d;
+};
+
+// Triangle in leaf order, 80 B: v0 and the two edges the reference recomputes for every test
+// (e1 = v1 − v0, e2 = v2 − v0: the same IEEE subtraction done once on the host), original id, object.
+struct __attribute__((aligned(16))) GTri {
+	double v0[3], e1[3], e2[3];
+	uint32_t orig, object;
+};
+
+constexpr int kStackDepth = 32;   // LDS traversal stack entries per lane (builder caps the depth)
+constexpr int kBlock = 256;       // threads per workgroup in every traversal kernel
+constexpr int kSentinel = INT32_MIN;
+constexpr uint32_t kMaxFirst = 1u << 27;
+
+struct SceneDev {
+	const GNode *nodes;
+	const GTri *tris;
+	int32_t root_ref; // kSentinel for an empty scene
+	float absmax;     // max |coordinate| of the scene bounds (for the per-ray box padding)
+};
+
+struct Hit {
+	double t, u, v;
+	uint32_t orig, object, pos; // orig == RTMI_MISS: no hit.  pos = index into the leaf-ordered array
+};
+
+// ---------------------------------------------------------------- exact triangle test
+// Render2/object.cpp:29-60 in double, same operation order; inclusive edges; 0.0 = miss.
+// u, v are only defined up to the point the reference assigns them.
+__device__ __forceinline__ double mt_exact(double ox, double oy, double oz, double dx, double dy, double dz,
+                                           const GTri &T, double &u, double &v) {
+	const double e1x = T.e1[0], e1y = T.e1[1], e1z = T.e1[2];
+	const double e2x = T.e2[0], e2y = T.e2[1], e2z = T.e2[2];
+	// pvec = dir ^ e2
+	const double px = dy * e2z - dz * e2y;
+	const double py = dz * e2x - dx * e2z;
+	const double pz = dx * e2y - dy * e2x;
+	const double det = (e1x * px) + (e1y * py) + (e1z * pz);
+	if (det < 1e-8 && det > -1e-8) return 0.0;
+	const double inv_det = 1.0 / det;
+	const double tx = ox - T.v0[0], ty = oy - T.v0[1], tz = oz - T.v0[2];
+	u = ((tx * px) + (ty * py) + (tz * pz)) * inv_det;
+	if (u < 0.0 || u > 1.0) return 0.0;
+	// qvec = tvec ^ e1
+	const double qx = ty * e1z - tz * e1y;
+	const double qy = tz * e1x - tx * e1z;
+	const double qz = tx * e1y - ty * e1x;
+	v = ((dx * qx) + (dy * qy) + (dz * qz)) * inv_det;
+	if (v < 0.0 || u + v > 1.0) return 0.0;
+	return ((e2x * qx) + (e2y * qy) + (e2z * qz)) * inv_det;
+}
+
+// ---------------------------------------------------------------- conservative fp32 slab test
+// The boxes only steer; the exact test decides.  They must never cull a triangle the exact test
+// would accept, so every slab is widened per ray by pad = 2^-18·(scene |coord| max + |o|max), which
+// dominates (a) the double->float rounding of o and d, (b) the <=5 fp32 roundings below and (c) the
+// distance by which a ray accepted by the double MT can miss the triangle's true bounds
+// (DESIGN.md §"Why the boxes are safe").  The pad is folded into two copies of the origin, so it
+// costs no instruction per box.
+struct RayF {
+	float opx, opy, opz; // o + pad
+	float omx, omy, omz; // o − pad
+	float ix, iy, iz;    // 1/d, |d| clamped away from 0 (no inf, hence no NaN from 0·inf)
+};
+
+__device__ __forceinline__ float safe_rcp(float d) {
+	const float tiny = 1e-20f;
+	if (fabsf(d) < tiny) d = (d < 0.f) ? -tiny : tiny;
+	return 1.0f / d;
+}
+
+__device__ __forceinline__ RayF make_rayf(double ox, double oy, double oz, double dx, double dy, double dz,
+                                          float absmax) {
+	const float fx = (float)ox, fy = (float)oy, fz = (float)oz;
+	const float pad = 3.814697265625e-06f * (absmax + fmaxf(fabsf(fx), fmaxf(fabsf(fy), fabsf(fz)))) + 1e-30f;
+	RayF r;
+	r.opx = fx + pad; r.opy = fy + pad; r.opz = fz + pad;
+	r.omx = fx - pad; r.omy = fy - pad; r.omz = fz - pad;
+	r.ix = safe_rcp((float)dx); r.iy = safe_rcp((float)dy); r.iz = safe_rcp((float)dz);
+	return r;
+}
+
+__device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz, const RayF &r,
+                                     float tbest, float &tnear) {
+	const float ax = (lox - r.opx) * r.ix, bx = (hix - r.omx) * r.ix;
+	const float ay = (loy - r.opy) * r.iy, by = (hiy - r.omy) * r.iy;
+	const float az = (loz - r.opz) * r.iz, bz = (hiz - r.omz) * r.iz;
+	const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+	const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tbest));
+	tnear = tn;
+	return tn <= tf;
+}
+
+// float >= x (x >= 0)
+__device__ __forceinline__ float f32_above(double x) { return __double2float_ru(x); }
+
+// ---------------------------------------------------------------- traversal
+// One ray per lane, per-lane stack in LDS (`stack` points at this lane's column, entries are
+// kBlock ints apart so a wave's pushes and pops hit 64 different banks).
+// ANY = false: closest hit — strict minimum of the positive t below tmax; equal t -> smaller
+//              original id (the in-order scan of Render2/object.cpp:143-168 keeps the first).
+// ANY = true : stop at the first triangle with 0 < t < tmax (Render2/shader.cpp:131,226).
+template <bool ANY>
+__device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, double oz, double dx, double dy,
+                                      double dz, double tmax, int *stack, Hit &h) {
+	h.t = 0.0; h.u = 0.0; h.v = 0.0;
+	h.orig = RTMI_MISS; h.object = RTMI_MISS; h.pos = RTMI_MISS;
+	double best = tmax;
+	float tbest = f32_above(best);
+	const RayF r = make_rayf(ox, oy, oz, dx, dy, dz, S.absmax);
+	int sp = 0;
+	int cur = S.root_ref;
+	while (cur != kSentinel) {
+		if (cur >= 0) {
+			const GNode *np = S.nodes + cur;
+			const float4 a = np->a, b = np->b, c = np->c;
+			const int4 d = np->d;
+			float t0, t1;
+			const bool h0 = slab(a.x, a.y, a.z, a.w, c.x, c.y, r, tbest, t0);
+			const bool h1 = slab(b.x, b.y, b.z, b.w, c.z, c.w, r, tbest, t1);
+			if (h0 && h1) {
+				const bool swap = t1 < t0;
+				cur = swap ? d.y : d.x;
+				stack[sp * kBlock] = swap ? d.x : d.y;
+				++sp;
+			} else if (h0) {
+				cur = d.x;
+			} else if (h1) {
+				cur = d.y;
+			} else if (sp > 0) {
+				--sp;
+				cur = stack[sp * kBlock];
+			} else {
+				cur = kSentinel;
+			}
+		} else {
+			const uint32_t code = ~(uint32_t)cur;
+			const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+			bool done = false;
+			for (uint32_t k = first; k < first + cnt; ++k) {
+				const GTri &T = S.tris[k];
+				double u = 0.0, v = 0.0;
+				const double t = mt_exact(ox, oy, oz, dx, dy, dz, T, u, v);
+				if (ANY) {
+					if (t > 0.0 && t < tmax) {
+						h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = k;
+						done = true;
+						break;
+					}
+				} else {
+					if (t > 0.0 && (best > t || (t == best && h.orig != RTMI_MISS && T.orig < h.orig))) {
+						best = t;
+						tbest = f32_above(best);
+						h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = k;
+					}
+				}
+			}
+			if (done) break;
+			if (sp > 0) {
+				--sp;
+				cur = stack[sp * kBlock];
+			} else {
+				cur = kSentinel;
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------- reference vector helpers (double)
+struct D3 { double x, y, z; };
+__device__ __forceinline__ D3 d3(double x, double y, double z) { D3 r = {x, y, z}; return r; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }     // vec3.h:22
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }     // vec3.h:26
+__device__ __forceinline__ D3 operator*(double s, D3 a) { return d3(s * a.x, s * a.y, s * a.z); }       // vec3.h:34
+__device__ __forceinline__ double dot(D3 a, D3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }   // vec3.h:42
+__device__ __forceinline__ D3 operator/(D3 a, double c) { return d3(a.x / c, a.y / c, a.z / c); }       // vec3.h:46
+__device__ __forceinline__ double len2(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }              // vec3.h:14
+__device__ __forceinline__ D3 unit(D3 a) {                                                              // vec3.h:98
+	const double d = len2(a);
+	return d > 0.0 ? a / sqrt(d) : d3(0, 0, 0);
+}
+
+} // namespace rtmi

@@ -1,0 +1,19 @@
+// Host-side declarations shared by the translation units of librtmi.
+#pragma once
+#include <string>
+
+#include "bvh_build.hpp"
+#include "rtmi_device.hpp"
+
+struct rtmi_scene {
+	rtmi::SceneDev dev;
+	uint64_t n_tris;
+	int device;
+	rtmi_scene_info info;
+};
+
+namespace rtmi {
+extern thread_local std::string g_err;
+int fail(const std::string &msg);        // records msg for rtmi_last_error(), returns -1
+int launch_check(const char *who);       // hipGetLastError() after a launch -> 0 / -1
+} // namespace rtmi

@@ -1,0 +1,418 @@
+// librtmi — radiosity: visibility, form factors and the Jacobi solve (include/rtmi.h), gfx950 only.
+//
+// Reference: Render2/radiosity.cpp.  Form factors are evaluated in double exactly as the reference
+// writes them (:305-333, :264-303) on sample points from a counter-based generator, then rounded
+// once to fp32 for storage; the solve streams that fp32 matrix from HBM once per sweep.
+#include "rtmi_host.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+struct rtmi_patches {
+	rtmi_scene *scene;
+	uint32_t n;
+	double *d_verts;   // n × 9: v1, v2, v3 in ORIGINAL order (util.cpp:113-115 samples from these)
+	double *d_normals; // n × 3: triNormal
+	double *d_area;    // n: vec3.h:116-118
+};
+
+namespace rtmi {
+
+constexpr double kEpsilon = 1.0e-5;       // Render2/base.h:57
+constexpr double kPi = 3.14159265358979;  // Render2/base.h:52
+constexpr uint32_t kLightStream = 0xFFFFFFFFu;
+
+struct PatchesDev {
+	const double *verts, *normals, *area;
+	uint32_t n;
+};
+
+// ---- counter-based sample generator (documented in DESIGN.md; the oracle restates it) ----------------
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+	z += 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+// uniform point on patch e for stream (seed, a, b, k, which); barycentric mix as Render2/util.cpp:113-115
+__device__ __forceinline__ D3 sample_point(const double *__restrict__ e, uint64_t seed, uint32_t a, uint32_t b,
+                                           uint32_t k, uint32_t which) {
+	uint64_t h = mix64(seed ^ (((uint64_t)a << 32) | b));
+	h = mix64(h ^ (((uint64_t)k << 32) | which));
+	double u = (double)(h >> 11) * 0x1.0p-53;
+	double v = (double)(mix64(h) >> 11) * 0x1.0p-53;
+	if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
+	const double w = 1.0 - u - v;
+	return d3((w * e[0]) + (u * e[3]) + (v * e[6]), (w * e[1]) + (u * e[4]) + (v * e[7]),
+	          (w * e[2]) + (u * e[5]) + (v * e[8]));
+}
+
+// Render2/radiosity.cpp:231-262 (+ :202-229, object.cpp:23): is xj on patch j visible from xi?
+__device__ __forceinline__ bool visible(const SceneDev &S, const PatchesDev &P, uint32_t j, D3 xi, D3 yi, int *stack) {
+	const D3 dir = unit(yi - xi);
+	const D3 org = xi + (kEpsilon * dir);
+	Hit h;
+	trace<false>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h);
+	if (h.orig == RTMI_MISS) return false;
+	// hit.point = o + (d·((v1 − o)·n)) / (n·d)   with the HIT triangle's first vertex and normal
+	const GTri &T = S.tris[h.pos];
+	const double *np = P.normals + 3 * (size_t)h.orig;
+	const D3 n = d3(np[0], np[1], np[2]);
+	const D3 v1 = d3(T.v0[0], T.v0[1], T.v0[2]);
+	const D3 p = org + (dot(v1 - org, n) * dir) / dot(n, dir);
+	const double *nj = P.normals + 3 * (size_t)j;
+	return sqrt(len2(p - yi)) < kEpsilon && dot(dir, d3(nj[0], nj[1], nj[2])) < 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_visible_points(SceneDev S, PatchesDev P, uint64_t m,
+                                                           const int32_t *__restrict__ ej, const double *__restrict__ xi,
+                                                           const double *__restrict__ xj, uint8_t *__restrict__ vis) {
+	__shared__ int stack[kStackDepth * kBlock];
+	const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (k >= m) return;
+	const D3 a = d3(xi[3 * k], xi[3 * k + 1], xi[3 * k + 2]), b = d3(xj[3 * k], xj[3 * k + 1], xj[3 * k + 2]);
+	vis[k] = visible(S, P, (uint32_t)ej[k], a, b, stack + threadIdx.x) ? 1 : 0;
+}
+
+// One lane per matrix entry (i, j): j runs fastest so a wave writes 256 contiguous bytes of a row of F
+// and its 64 × S visibility rays leave the same patch i.
+//   j <  n_patches, i != j : Render2/radiosity.cpp:305-333 (findFormFactorTerm)
+//   j == n_patches (light) : Render2/radiosity.cpp:264-303 (findFormFactorTermWithLight)
+//   i == n_patches or i == j : 0   (:382, :391-393)
+__global__ __launch_bounds__(kBlock) void k_form_factors(SceneDev S, PatchesDev P, bool has_light, double cx, double cy,
+                                                         double cz, uint32_t samples, uint32_t light_samples,
+                                                         uint64_t seed, uint32_t flags, uint32_t row0, uint32_t n_rows,
+                                                         uint32_t n, float *__restrict__ F, uint64_t ld) {
+	__shared__ int stack_all[kStackDepth * kBlock];
+	int *stack = stack_all + threadIdx.x;
+	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (idx >= (uint64_t)n_rows * n) return;
+	const uint32_t r = (uint32_t)(idx / n), j = (uint32_t)(idx % n), i = row0 + r;
+	double out = 0.0;
+	if (i < P.n && j < P.n && i != j) {
+		const double *ei = P.verts + 9 * (size_t)i, *ejp = P.verts + 9 * (size_t)j;
+		const D3 ni = d3(P.normals[3 * (size_t)i], P.normals[3 * (size_t)i + 1], P.normals[3 * (size_t)i + 2]);
+		const D3 nj = d3(P.normals[3 * (size_t)j], P.normals[3 * (size_t)j + 1], P.normals[3 * (size_t)j + 2]);
+		const double area_j = P.area[j];
+		double ff = 0.0;
+		for (uint32_t k = 0; k < samples; ++k) {
+			const D3 xi = sample_point(ei, seed, i, j, k, 0), xj = sample_point(ejp, seed, i, j, k, 1);
+			if (visible(S, P, j, xi, xj, stack)) {
+				const D3 ab = xi - xj;
+				const double dist2 = dot(ab, ab);
+				const double c1 = dot(unit(xj - xi), ni);
+				const double c2 = dot(unit(xi - xj), nj);
+				const double cosFactor = c1 * c2;
+				const double delF = (c1 < 0.0 || c2 < 0.0) ? 0.0 : cosFactor / ((kPi * dist2) + (area_j / (int)samples));
+				if (delF > 0.0) ff += delF;
+			}
+		}
+		ff = ff / ((double)samples);
+		out = ff * area_j;
+	} else if (has_light && i < P.n && j == P.n) {
+		const double *ei = P.verts + 9 * (size_t)i;
+		const D3 ni = d3(P.normals[3 * (size_t)i], P.normals[3 * (size_t)i + 1], P.normals[3 * (size_t)i + 2]);
+		const D3 C = d3(cx, cy, cz);
+		const bool mean = (flags & RTMI_FF_LIGHT_MEAN) != 0;
+		double ff = 0.0;
+		// the reference zeroes its accumulator inside the loop (:276): only the last sample survives
+		for (uint32_t k = mean ? 0u : light_samples - 1; k < light_samples; ++k) {
+			const D3 x = sample_point(ei, seed, i, kLightStream, k, 0);
+			const D3 dir = unit(C - x);
+			const D3 org = x + (kEpsilon * ni);
+			Hit h;
+			trace<true>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h);
+			if (h.orig == RTMI_MISS) {
+				const double L = sqrt(len2(C - x));
+				const double tmp = ((1.0 / (4.0 * kPi)) * (dot(dir, ni) / (L * L)));
+				if (tmp > 0.0) ff += tmp;
+			}
+		}
+		out = light_samples ? ff / ((double)light_samples) : 0.0;
+	}
+	F[(uint64_t)r * ld + j] = (float)out;
+}
+
+// ---- Jacobi sweep: HBM-bound streaming of F -------------------------------------------------------------
+// A workgroup (4 waves) owns kRows consecutive rows.  The 4 waves interleave 256-column chunks of those
+// rows: in every step a lane loads one float4 of each of the kRows rows (kRows independent 16-B loads
+// in flight, 1 KiB per wave-instruction, rows streamed sequentially so HBM pages stay open) and the 12
+// matching floats of B (3 × float4, L1/L2 hits shared by the block's rows).  Accumulation in double.
+constexpr int kRows = 8;
+
+__global__ __launch_bounds__(kBlock) void k_jacobi_sweep(const float *__restrict__ F, uint64_t ld, uint32_t n, uint32_t row0,
+                                                         uint32_t n_rows, double rho0, double rho1, double rho2,
+                                                         const float *__restrict__ E, const float *__restrict__ Bold,
+                                                         float *__restrict__ Bnew, double *__restrict__ norms) {
+	__shared__ double red[4][kRows][3];
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const uint32_t r0 = blockIdx.x * kRows; // local row
+	double acc[kRows][3];
+#pragma unroll
+	for (int r = 0; r < kRows; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0;
+	const float *rowp[kRows];
+#pragma unroll
+	for (int r = 0; r < kRows; ++r) rowp[r] = F + (uint64_t)min(r0 + r, n_rows - 1) * ld; // tail rows re-read the last row
+	const uint32_t n4 = n & ~3u;
+	for (uint32_t c = (wave * 64 + lane) * 4; c < n4; c += 4 * kBlock) {
+		float4 f[kRows];
+#pragma unroll
+		for (int r = 0; r < kRows; ++r) f[r] = *reinterpret_cast<const float4 *>(rowp[r] + c);
+		const float4 b0 = *reinterpret_cast<const float4 *>(Bold + 3 * (size_t)c);
+		const float4 b1 = *reinterpret_cast<const float4 *>(Bold + 3 * (size_t)c + 4);
+		const float4 b2 = *reinterpret_cast<const float4 *>(Bold + 3 * (size_t)c + 8);
+		// [c][0..2], [c+1][0..2], ... interleaved RGB
+		const double B00 = b0.x, B01 = b0.y, B02 = b0.z, B10 = b0.w, B11 = b1.x, B12 = b1.y;
+		const double B20 = b1.z, B21 = b1.w, B22 = b2.x, B30 = b2.y, B31 = b2.z, B32 = b2.w;
+#pragma unroll
+		for (int r = 0; r < kRows; ++r) {
+			const double fx = f[r].x, fy = f[r].y, fz = f[r].z, fw = f[r].w;
+			acc[r][0] = fma(fx, B00, acc[r][0]); acc[r][1] = fma(fx, B01, acc[r][1]); acc[r][2] = fma(fx, B02, acc[r][2]);
+			acc[r][0] = fma(fy, B10, acc[r][0]); acc[r][1] = fma(fy, B11, acc[r][1]); acc[r][2] = fma(fy, B12, acc[r][2]);
+			acc[r][0] = fma(fz, B20, acc[r][0]); acc[r][1] = fma(fz, B21, acc[r][1]); acc[r][2] = fma(fz, B22, acc[r][2]);
+			acc[r][0] = fma(fw, B30, acc[r][0]); acc[r][1] = fma(fw, B31, acc[r][1]); acc[r][2] = fma(fw, B32, acc[r][2]);
+		}
+	}
+	// columns n4..n-1 (n not a multiple of 4): one lane each
+	if (wave == 0 && lane < (n - n4)) {
+		const uint32_t c = n4 + lane;
+#pragma unroll
+		for (int r = 0; r < kRows; ++r) {
+			const double f = rowp[r][c];
+			acc[r][0] = fma(f, (double)Bold[3 * (size_t)c], acc[r][0]);
+			acc[r][1] = fma(f, (double)Bold[3 * (size_t)c + 1], acc[r][1]);
+			acc[r][2] = fma(f, (double)Bold[3 * (size_t)c + 2], acc[r][2]);
+		}
+	}
+	// wave reduction (butterfly over 64 lanes), then across the 4 waves through LDS
+#pragma unroll
+	for (int r = 0; r < kRows; ++r)
+#pragma unroll
+		for (int ch = 0; ch < 3; ++ch) {
+			double x = acc[r][ch];
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+			if (lane == 0) red[wave][r][ch] = x;
+		}
+	__syncthreads();
+	if (wave == 0) { // whole wave takes part in the shuffles; lanes >= 24 contribute zeros
+		const uint32_t r = lane / 3, ch = lane % 3;
+		double d2 = 0.0, b2 = 0.0, dmax = 0.0;
+		if (lane < kRows * 3 && r0 + r < n_rows) {
+			const double s = red[0][r][ch] + red[1][r][ch] + red[2][r][ch] + red[3][r][ch];
+			const size_t gi = 3 * (size_t)(row0 + r0 + r) + ch;
+			const double rho = ch == 0 ? rho0 : (ch == 1 ? rho1 : rho2);
+			const float bn = (float)((double)E[gi] + rho * s);
+			const double d = (double)bn - (double)Bold[gi];
+			Bnew[gi] = bn;
+			d2 = d * d;
+			b2 = (double)bn * (double)bn;
+			dmax = fabs(d);
+		}
+#pragma unroll
+		for (int off = 16; off > 0; off >>= 1) {
+			d2 += __shfl_xor(d2, off, 64);
+			b2 += __shfl_xor(b2, off, 64);
+			dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+		}
+		if (lane == 0) { // one atomic per block and quantity
+			atomicAdd(&norms[0], d2);
+			atomicAdd(&norms[1], b2);
+			atomicMax(reinterpret_cast<unsigned long long *>(&norms[2]), (unsigned long long)__double_as_longlong(dmax));
+		}
+	}
+}
+
+static int check_patches(const rtmi_patches *p, const char *who) {
+	if (!p) return fail(std::string(who) + ": patches is NULL");
+	int dev = -1;
+	if (hipGetDevice(&dev) != hipSuccess || dev != p->scene->device)
+		return fail(std::string(who) + ": the patches live on another device than the current one");
+	return 0;
+}
+
+static PatchesDev pdev(const rtmi_patches *p) {
+	PatchesDev d;
+	d.verts = p->d_verts; d.normals = p->d_normals; d.area = p->d_area; d.n = p->n;
+	return d;
+}
+
+} // namespace rtmi
+
+using namespace rtmi;
+
+extern "C" {
+
+rtmi_patches *rtmi_patches_create(rtmi_scene *s, const double *verts, const double *normals) {
+	if (!s || !verts || !normals) { fail("rtmi_patches_create: NULL argument"); return nullptr; }
+	int dev = -1;
+	if (hipGetDevice(&dev) != hipSuccess || dev != s->device) { fail("rtmi_patches_create: wrong current device"); return nullptr; }
+	if (s->n_tris == 0 || s->n_tris > 0x7fffffffu) { fail("rtmi_patches_create: scene has no (or too many) triangles"); return nullptr; }
+	const uint32_t n = (uint32_t)s->n_tris;
+	// Area(v1,v2,v3) = Length((v2−v1)^(v3−v1)) / 2, Render2/vec3.h:116-118, same operation order (host IEEE double)
+	std::vector<double> area(n);
+	for (uint32_t i = 0; i < n; ++i) {
+		const double *p = verts + 9 * (size_t)i;
+		const double ax = p[3] - p[0], ay = p[4] - p[1], az = p[5] - p[2];
+		const double bx = p[6] - p[0], by = p[7] - p[1], bz = p[8] - p[2];
+		const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+		area[i] = std::sqrt(cx * cx + cy * cy + cz * cz) / 2.0;
+	}
+	rtmi_patches *P = new rtmi_patches();
+	P->scene = s;
+	P->n = n;
+	P->d_verts = P->d_normals = P->d_area = nullptr;
+	bool ok = hipMalloc(&P->d_verts, sizeof(double) * 9 * (size_t)n) == hipSuccess &&
+	          hipMalloc(&P->d_normals, sizeof(double) * 3 * (size_t)n) == hipSuccess &&
+	          hipMalloc(&P->d_area, sizeof(double) * (size_t)n) == hipSuccess;
+	ok = ok && hipMemcpy(P->d_verts, verts, sizeof(double) * 9 * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && hipMemcpy(P->d_normals, normals, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && hipMemcpy(P->d_area, area.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
+	if (!ok) {
+		rtmi_patches_destroy(P);
+		fail("rtmi_patches_create: device allocation or upload failed");
+		return nullptr;
+	}
+	return P;
+}
+
+void rtmi_patches_destroy(rtmi_patches *P) {
+	if (!P) return;
+	if (P->d_verts) (void)hipFree(P->d_verts);
+	if (P->d_normals) (void)hipFree(P->d_normals);
+	if (P->d_area) (void)hipFree(P->d_area);
+	delete P;
+}
+
+int rtmi_visible_points(rtmi_patches *P, uint64_t m, const int32_t *ej, const double *xi, const double *xj, uint8_t *vis) {
+	const char *who = "rtmi_visible_points";
+	if (check_patches(P, who)) return -1;
+	if (m == 0) return 0;
+	if (!ej || !xi || !xj || !vis) return fail(std::string(who) + ": NULL buffer");
+	for (uint64_t k = 0; k < m; ++k)
+		if (ej[k] < 0 || (uint32_t)ej[k] >= P->n) return fail(std::string(who) + ": patch index out of range");
+	int32_t *d_ej = nullptr;
+	double *d_xi = nullptr, *d_xj = nullptr;
+	uint8_t *d_vis = nullptr;
+	bool ok = hipMalloc(&d_ej, 4 * m) == hipSuccess && hipMalloc(&d_xi, 24 * m) == hipSuccess &&
+	          hipMalloc(&d_xj, 24 * m) == hipSuccess && hipMalloc(&d_vis, m) == hipSuccess;
+	ok = ok && hipMemcpy(d_ej, ej, 4 * m, hipMemcpyHostToDevice) == hipSuccess &&
+	     hipMemcpy(d_xi, xi, 24 * m, hipMemcpyHostToDevice) == hipSuccess &&
+	     hipMemcpy(d_xj, xj, 24 * m, hipMemcpyHostToDevice) == hipSuccess;
+	int rc = ok ? 0 : fail(std::string(who) + ": device allocation or upload failed");
+	if (!rc) {
+		hipLaunchKernelGGL(k_visible_points, dim3((uint32_t)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
+		                   P->scene->dev, pdev(P), m, d_ej, d_xi, d_xj, d_vis);
+		rc = launch_check(who);
+	}
+	if (!rc && hipMemcpy(vis, d_vis, m, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(std::string(who) + ": D2H copy failed");
+	if (d_ej) (void)hipFree(d_ej);
+	if (d_xi) (void)hipFree(d_xi);
+	if (d_xj) (void)hipFree(d_xj);
+	if (d_vis) (void)hipFree(d_vis);
+	return rc;
+}
+
+int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t samples, uint32_t light_samples,
+                          uint64_t seed, uint32_t flags, uint32_t row0, uint32_t n_rows, float *d_F, uint64_t ld,
+                          void *stream) {
+	const char *who = "rtmi_form_factors_dev";
+	if (check_patches(P, who)) return -1;
+	const uint32_t n = P->n + (light_center ? 1u : 0u);
+	if (n_rows == 0) return 0;
+	if (!d_F) return fail(std::string(who) + ": d_F is NULL");
+	if (samples == 0) return fail(std::string(who) + ": samples must be >= 1");
+	if ((uint64_t)row0 + n_rows > n) return fail(std::string(who) + ": row range exceeds n");
+	if (ld < n) return fail(std::string(who) + ": ld < n");
+	const uint64_t total = (uint64_t)n_rows * n, grid = (total + kBlock - 1) / kBlock;
+	if (grid > 0x7fffffffull) return fail(std::string(who) + ": too many entries for one launch; shard the rows");
+	const double cx = light_center ? light_center[0] : 0.0, cy = light_center ? light_center[1] : 0.0,
+	             cz = light_center ? light_center[2] : 0.0;
+	hipLaunchKernelGGL(k_form_factors, dim3((uint32_t)grid), dim3(kBlock), 0, (hipStream_t)stream, P->scene->dev, pdev(P),
+	                   light_center != nullptr, cx, cy, cz, samples, light_samples, seed, flags, row0, n_rows, n, d_F, ld);
+	return launch_check(who);
+}
+
+int rtmi_jacobi_sweep_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3],
+                          const float *d_E, const float *d_B_old, float *d_B_new, double *d_norms, void *stream) {
+	const char *who = "rtmi_jacobi_sweep_dev";
+	if (n_rows == 0) return 0;
+	if (!d_F || !rho || !d_E || !d_B_old || !d_B_new || !d_norms) return fail(std::string(who) + ": NULL argument");
+	if ((uint64_t)row0 + n_rows > n) return fail(std::string(who) + ": row range exceeds n");
+	if (ld < n) return fail(std::string(who) + ": ld < n");
+	if ((ld & 3u) || ((uintptr_t)d_F & 15u) || ((uintptr_t)d_B_old & 15u))
+		return fail(std::string(who) + ": d_F / d_B_old must be 16-byte aligned and ld a multiple of 4");
+	if (d_B_old == d_B_new) return fail(std::string(who) + ": Jacobi needs distinct B_old and B_new");
+	const uint32_t grid = (n_rows + kRows - 1) / kRows;
+	hipLaunchKernelGGL(k_jacobi_sweep, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, d_F, ld, n, row0, n_rows, rho[0], rho[1],
+	                   rho[2], d_E, d_B_old, d_B_new, d_norms);
+	return launch_check(who);
+}
+
+int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3],
+                             const float *d_E, float *d_B, float tol_rel, uint32_t max_sweeps, uint32_t check_every,
+                             rtmi_exchange_fn exchange, void *user, rtmi_solve_stats *stats, void *stream) {
+	const char *who = "rtmi_radiosity_solve_dev";
+	if (!d_F || !rho || !d_E || !d_B) return fail(std::string(who) + ": NULL argument");
+	if (n == 0) return fail(std::string(who) + ": n == 0");
+	if (check_every == 0) check_every = 1;
+	hipStream_t st = (hipStream_t)stream;
+	const size_t vb = sizeof(float) * 3 * (size_t)n;
+	float *d_tmp = nullptr;
+	double *d_norms = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	int rc = 0;
+	if (hipMalloc(&d_tmp, vb) != hipSuccess || hipMalloc(&d_norms, 3 * sizeof(double)) != hipSuccess)
+		rc = fail(std::string(who) + ": hipMalloc failed");
+	if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail(std::string(who) + ": hipEventCreate failed");
+	// B_0 = E (Render2/radiosity.cpp:506-509)
+	if (!rc && hipMemcpyAsync(d_B, d_E, vb, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = fail(std::string(who) + ": copy failed");
+	float *cur = d_B, *nxt = d_tmp;
+	uint32_t sweeps = 0;
+	double rel = INFINITY, mx = INFINITY;
+	if (!rc) (void)hipEventRecord(e0, st);
+	while (!rc && sweeps < max_sweeps) {
+		const bool check = ((sweeps + 1) % check_every == 0) || sweeps + 1 == max_sweeps;
+		if (hipMemsetAsync(d_norms, 0, 3 * sizeof(double), st) != hipSuccess) { rc = fail(std::string(who) + ": memset failed"); break; }
+		rc = rtmi_jacobi_sweep_dev(d_F, ld, n, row0, n_rows, rho, d_E, cur, nxt, d_norms, stream);
+		if (rc) break;
+		if (exchange) {
+			if (exchange(user, nxt, d_norms, stream) != 0) { rc = fail(std::string(who) + ": exchange callback failed"); break; }
+		}
+		std::swap(cur, nxt);
+		++sweeps;
+		if (check) {
+			double h[3];
+			if (hipMemcpyAsync(h, d_norms, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+				rc = fail(std::string(who) + ": reading the norms failed: " + hipGetErrorString(hipGetLastError()));
+				break;
+			}
+			rel = h[1] > 0.0 ? std::sqrt(h[0] / h[1]) : 0.0;
+			mx = h[2];
+			if (rel <= (double)tol_rel) break;
+		}
+	}
+	if (!rc) {
+		(void)hipEventRecord(e1, st);
+		if (cur != d_B && hipMemcpyAsync(d_B, cur, vb, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = fail(std::string(who) + ": copy failed");
+		if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(std::string(who) + ": synchronize failed: " + hipGetErrorString(hipGetLastError()));
+	}
+	if (!rc && stats) {
+		float ms = 0.f;
+		(void)hipEventElapsedTime(&ms, e0, e1);
+		stats->sweeps = sweeps;
+		stats->rel_change = rel;
+		stats->max_change = mx;
+		stats->seconds = ms * 1e-3;
+		stats->bytes_per_sweep = 4.0 * (double)n_rows * (double)n;
+	}
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	if (d_tmp) (void)hipFree(d_tmp);
+	if (d_norms) (void)hipFree(d_norms);
+	return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,352 @@
+// librtmi — scene upload, closest-hit / any-hit / primary-ray kernels and their C ABI (include/rtmi.h).
+// gfx950 (MI355X) only; build: see raytracer_amd/csrc/Makefile.
+#include "rtmi_host.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace rtmi {
+
+thread_local std::string g_err;
+
+int fail(const std::string &msg) {
+	g_err = msg;
+	return -1;
+}
+
+// ------------------------------------------------------------------------------------------- kernels
+// Rays from a buffer: lane k of the grid takes ray k (callers that care about coherence sort first).
+template <bool ANY>
+__global__ __launch_bounds__(kBlock) void k_trace_rays(SceneDev S, const rtmi_ray *__restrict__ rays, uint64_t n,
+                                                       rtmi_hit *__restrict__ out, uint8_t *__restrict__ occluded) {
+	__shared__ int stack[kStackDepth * kBlock];
+	const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (k >= n) return;
+	const rtmi_ray R = rays[k];
+	double tmax = R.tmax;
+	if (!(tmax > 0.0) || tmax > RTMI_INFINITY) tmax = RTMI_INFINITY;
+	Hit h;
+	trace<ANY>(S, R.o[0], R.o[1], R.o[2], R.d[0], R.d[1], R.d[2], tmax, stack + threadIdx.x, h);
+	if (ANY) {
+		occluded[k] = h.orig != RTMI_MISS ? 1 : 0;
+	} else {
+		rtmi_hit o;
+		o.t = h.t; o.u = (float)h.u; o.v = (float)h.v; o.tri = h.orig; o.object = h.object;
+		out[k] = o;
+	}
+}
+
+// Render2/rasterizer.cpp:230 — dir(i,j) = Unit(O + (j+sx)·dR − (i+sy)·dU), origin = eye.
+__device__ __forceinline__ D3 primary_dir(const rtmi_camera &c, uint32_t i, uint32_t j, double sx, double sy) {
+	const D3 O = d3(c.O[0], c.O[1], c.O[2]), dR = d3(c.dR[0], c.dR[1], c.dR[2]), dU = d3(c.dU[0], c.dU[1], c.dU[2]);
+	return unit((O + (j + sx) * dR) - (i + sy) * dU);
+}
+
+// Primary rays generated in registers, 0 input bytes per ray.  A workgroup owns a 16×16 pixel
+// block of one image tile, each of its 4 waves an 8×8 pixel square: 64 nearly parallel rays walk
+// the same nodes, so a wave's node fetches collapse to a few cache lines.
+__global__ __launch_bounds__(kBlock) void k_primary_closest(SceneDev S, rtmi_camera cam, double sx, double sy,
+                                                            uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x,
+                                                            uint32_t tile_first, uint32_t tile_stride,
+                                                            uint32_t blocks_x, uint32_t blocks_per_tile,
+                                                            rtmi_hit *__restrict__ out) {
+	__shared__ int stack[kStackDepth * kBlock];
+	const uint32_t local_tile = blockIdx.x / blocks_per_tile, b = blockIdx.x % blocks_per_tile;
+	const uint32_t tile = tile_first + local_tile * tile_stride;
+	const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const uint32_t lx = (b % blocks_x) * 16 + (wave & 1) * 8 + (lane & 7);
+	const uint32_t ly = (b / blocks_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
+	const uint32_t j = tx * tile_w + lx, i = ty * tile_h + ly;
+	if (lx >= tile_w || ly >= tile_h || j >= cam.x_res || i >= cam.y_res) return;
+	const D3 d = primary_dir(cam, i, j, sx, sy);
+	Hit h;
+	trace<false>(S, cam.eye[0], cam.eye[1], cam.eye[2], d.x, d.y, d.z, RTMI_INFINITY, stack + threadIdx.x, h);
+	rtmi_hit o;
+	o.t = h.t; o.u = (float)h.u; o.v = (float)h.v; o.tri = h.orig; o.object = h.object;
+	out[(uint64_t)i * cam.x_res + j] = o;
+}
+
+__global__ void k_primary_rays(rtmi_camera cam, double sx, double sy, rtmi_ray *__restrict__ rays) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t n = (uint64_t)cam.x_res * cam.y_res;
+	if (k >= n) return;
+	const uint32_t i = (uint32_t)(k / cam.x_res), j = (uint32_t)(k % cam.x_res);
+	const D3 d = primary_dir(cam, i, j, sx, sy);
+	rtmi_ray R;
+	R.o[0] = cam.eye[0]; R.o[1] = cam.eye[1]; R.o[2] = cam.eye[2];
+	R.d[0] = d.x; R.d[1] = d.y; R.d[2] = d.z;
+	R.tmax = RTMI_INFINITY;
+	R.reserved = 0.0;
+	rays[k] = R;
+}
+
+// ------------------------------------------------------------------------------------------- scene
+static unsigned env_uint(const char *name, unsigned dflt) {
+	const char *s = std::getenv(name);
+	if (!s || !*s) return dflt;
+	long v = std::strtol(s, nullptr, 10);
+	return v > 0 ? (unsigned)v : dflt;
+}
+
+static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t n) {
+	if (n > 0 && !xyz) { fail("rtmi_scene_create: tri_xyz is NULL"); return nullptr; }
+	if (n >= kMaxFirst) { fail("rtmi_scene_create: more than 2^27-1 triangles"); return nullptr; }
+	for (uint64_t i = 0; i < 9 * n; ++i)
+		if (!std::isfinite(xyz[i])) { fail("rtmi_scene_create: non-finite vertex coordinate"); return nullptr; }
+	auto t0 = std::chrono::steady_clock::now();
+	const unsigned leaf = std::min(8u, env_uint("RTMI_LEAF", 4));
+	const unsigned threads = std::min(env_uint("RTMI_BUILD_THREADS", std::max(1u, std::thread::hardware_concurrency())), 16u);
+	Bvh2 bvh = build_bvh2(xyz, n, leaf, kStackDepth - 2, threads);
+	if (n > 0 && bvh.depth > (uint32_t)kStackDepth - 1) { fail("rtmi_scene_create: BVH deeper than the traversal stack"); return nullptr; }
+
+	rtmi_scene *s = new rtmi_scene();
+	s->n_tris = n;
+	s->info.n_tris = n;
+	s->info.n_leaves = bvh.n_leaves;
+	s->info.max_depth = bvh.depth;
+	s->info.max_leaf_size = bvh.max_leaf;
+	std::memcpy(s->info.scene_lo, bvh.lo, sizeof bvh.lo);
+	std::memcpy(s->info.scene_hi, bvh.hi, sizeof bvh.hi);
+	if (hipGetDevice(&s->device) != hipSuccess) { delete s; fail("hipGetDevice failed"); return nullptr; }
+	s->dev.nodes = nullptr; s->dev.tris = nullptr; s->dev.root_ref = kSentinel; s->dev.absmax = 0.f;
+	if (n == 0) return s;
+
+	// leaf-ordered triangles
+	std::vector<GTri> tris(n);
+	for (uint64_t k = 0; k < n; ++k) {
+		const uint32_t id = bvh.order[k];
+		const double *p = xyz + 9 * (uint64_t)id;
+		GTri &T = tris[k];
+		for (int a = 0; a < 3; ++a) {
+			T.v0[a] = p[a];
+			T.e1[a] = p[3 + a] - p[a]; // Render2/object.cpp:36
+			T.e2[a] = p[6 + a] - p[a]; // Render2/object.cpp:37
+		}
+		T.orig = id;
+		T.object = obj ? obj[id] : 0u;
+	}
+	// inner nodes in depth-first order (a node's near subtree follows it in memory)
+	auto ref_of_leaf = [](const BuildNode &b) { return (int32_t) ~((b.first << 3) | (b.count - 1)); };
+	std::vector<GNode> nodes;
+	const BuildNode &root = bvh.nodes[0];
+	int32_t root_ref;
+	if (root.left < 0) {
+		root_ref = ref_of_leaf(root);
+	} else {
+		nodes.reserve(bvh.nodes.size() / 2 + 1);
+		struct Item { uint32_t build_id; int32_t out_id; };
+		std::vector<Item> todo;
+		nodes.emplace_back();
+		todo.push_back({0u, 0});
+		while (!todo.empty()) {
+			Item it = todo.back();
+			todo.pop_back();
+			const BuildNode &b = bvh.nodes[it.build_id];
+			const BuildNode &c0 = bvh.nodes[b.left], &c1 = bvh.nodes[b.right];
+			int32_t r0, r1;
+			// allocate right first so that the left child is processed (and laid out) first
+			if (c1.left < 0) r1 = ref_of_leaf(c1);
+			else { r1 = (int32_t)nodes.size(); nodes.emplace_back(); todo.push_back({(uint32_t)b.right, r1}); }
+			if (c0.left < 0) r0 = ref_of_leaf(c0);
+			else { r0 = (int32_t)nodes.size(); nodes.emplace_back(); todo.push_back({(uint32_t)b.left, r0}); }
+			GNode g;
+			g.a = make_float4(c0.lo[0], c0.hi[0], c0.lo[1], c0.hi[1]);
+			g.b = make_float4(c1.lo[0], c1.hi[0], c1.lo[1], c1.hi[1]);
+			g.c = make_float4(c0.lo[2], c0.hi[2], c1.lo[2], c1.hi[2]);
+			g.d = make_int4(r0, r1, 0, 0);
+			nodes[it.out_id] = g;
+		}
+		root_ref = 0;
+	}
+	float absmax = 0.f;
+	for (int a = 0; a < 3; ++a) absmax = std::max(absmax, std::max(std::fabs(bvh.lo[a]), std::fabs(bvh.hi[a])));
+
+	GNode *d_nodes = nullptr;
+	GTri *d_tris = nullptr;
+	const size_t nb = std::max<size_t>(1, nodes.size()) * sizeof(GNode), tb = tris.size() * sizeof(GTri);
+	if (hipMalloc(&d_nodes, nb) != hipSuccess || hipMalloc(&d_tris, tb) != hipSuccess) {
+		if (d_nodes) (void)hipFree(d_nodes);
+		delete s;
+		fail("rtmi_scene_create: hipMalloc failed");
+		return nullptr;
+	}
+	bool ok = true;
+	if (!nodes.empty()) ok = ok && hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(GNode), hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && hipMemcpy(d_tris, tris.data(), tb, hipMemcpyHostToDevice) == hipSuccess;
+	if (!ok) {
+		(void)hipFree(d_nodes); (void)hipFree(d_tris);
+		delete s;
+		fail("rtmi_scene_create: upload failed");
+		return nullptr;
+	}
+	s->dev.nodes = d_nodes; s->dev.tris = d_tris; s->dev.root_ref = root_ref; s->dev.absmax = absmax;
+	s->info.n_nodes = nodes.size();
+	s->info.device_bytes = nb + tb;
+	s->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	return s;
+}
+
+static int check_scene(const rtmi_scene *s, const char *who) {
+	if (!s) return fail(std::string(who) + ": scene is NULL");
+	int dev = -1;
+	if (hipGetDevice(&dev) != hipSuccess) return fail(std::string(who) + ": hipGetDevice failed");
+	if (dev != s->device) return fail(std::string(who) + ": the scene lives on another device than the current one");
+	return 0;
+}
+
+int launch_check(const char *who) {
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return fail(std::string(who) + ": launch failed: " + hipGetErrorString(e));
+	return 0;
+}
+
+template <bool ANY>
+static int trace_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, rtmi_hit *d_out, uint8_t *d_occ, void *stream,
+                     const char *who) {
+	if (check_scene(s, who)) return -1;
+	if (n == 0) return 0;
+	if (!d_rays || (ANY ? !d_occ : !d_out)) return fail(std::string(who) + ": NULL buffer");
+	if (n > (uint64_t)0x7fffffff * kBlock) return fail(std::string(who) + ": too many rays for one launch");
+	const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
+	hipLaunchKernelGGL(k_trace_rays<ANY>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s->dev, d_rays, n, d_out, d_occ);
+	return launch_check(who);
+}
+
+// host-pointer convenience wrappers: stage through device buffers, synchronous
+template <bool ANY>
+static int trace_host(rtmi_scene *s, const rtmi_ray *rays, uint64_t n, rtmi_hit *out, uint8_t *occ, const char *who) {
+	if (check_scene(s, who)) return -1;
+	if (n == 0) return 0;
+	if (!rays || (ANY ? !occ : !out)) return fail(std::string(who) + ": NULL buffer");
+	rtmi_ray *d_rays = nullptr;
+	void *d_res = nullptr;
+	const size_t rb = n * sizeof(rtmi_ray), ob = ANY ? n : n * sizeof(rtmi_hit);
+	if (hipMalloc(&d_rays, rb) != hipSuccess) return fail(std::string(who) + ": hipMalloc failed");
+	if (hipMalloc(&d_res, ob) != hipSuccess) { (void)hipFree(d_rays); return fail(std::string(who) + ": hipMalloc failed"); }
+	int rc = 0;
+	if (hipMemcpy(d_rays, rays, rb, hipMemcpyHostToDevice) != hipSuccess) rc = fail(std::string(who) + ": H2D copy failed");
+	if (!rc) rc = trace_dev<ANY>(s, d_rays, n, (rtmi_hit *)d_res, (uint8_t *)d_res, nullptr, who);
+	if (!rc && hipMemcpy(ANY ? (void *)occ : (void *)out, d_res, ob, hipMemcpyDeviceToHost) != hipSuccess)
+		rc = fail(std::string(who) + ": D2H copy failed: " + hipGetErrorString(hipGetLastError()));
+	(void)hipFree(d_rays);
+	(void)hipFree(d_res);
+	return rc;
+}
+
+} // namespace rtmi
+
+using namespace rtmi;
+
+extern "C" {
+
+const char *rtmi_last_error(void) { return g_err.c_str(); }
+
+int rtmi_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return n;
+}
+
+rtmi_scene *rtmi_scene_create(const double *tri_xyz, const uint32_t *tri_object, uint64_t n_tris) {
+	return scene_create(tri_xyz, tri_object, n_tris);
+}
+
+void rtmi_scene_destroy(rtmi_scene *s) {
+	if (!s) return;
+	if (s->dev.nodes) (void)hipFree((void *)s->dev.nodes);
+	if (s->dev.tris) (void)hipFree((void *)s->dev.tris);
+	delete s;
+}
+
+int rtmi_scene_get_info(const rtmi_scene *s, rtmi_scene_info *out) {
+	if (!s || !out) return fail("rtmi_scene_get_info: NULL argument");
+	*out = s->info;
+	return 0;
+}
+
+int rtmi_closest_hit(rtmi_scene *s, const rtmi_ray *rays, uint64_t n, rtmi_hit *out) {
+	return trace_host<false>(s, rays, n, out, nullptr, "rtmi_closest_hit");
+}
+int rtmi_closest_hit_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, rtmi_hit *d_out, void *stream) {
+	return trace_dev<false>(s, d_rays, n, d_out, nullptr, stream, "rtmi_closest_hit_dev");
+}
+int rtmi_any_hit(rtmi_scene *s, const rtmi_ray *rays, uint64_t n, uint8_t *occluded) {
+	return trace_host<true>(s, rays, n, nullptr, occluded, "rtmi_any_hit");
+}
+int rtmi_any_hit_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, uint8_t *d_occluded, void *stream) {
+	return trace_dev<true>(s, d_rays, n, nullptr, d_occluded, stream, "rtmi_any_hit_dev");
+}
+
+// Render2/rasterizer.cpp:40-56 with the reference's Vec3 operators (vec3.h) restated on the host.
+int rtmi_camera_setup(const double eye[3], const double lookat[3], const double up[3], double vpdist,
+                      const double x_win[2], const double y_win[2], uint32_t x_res, uint32_t y_res, rtmi_camera *out) {
+	if (!eye || !lookat || !up || !x_win || !y_win || !out) return fail("rtmi_camera_setup: NULL argument");
+	if (x_res == 0 || y_res == 0) return fail("rtmi_camera_setup: zero resolution");
+	struct V { double x, y, z; };
+	auto sub = [](V a, V b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; };
+	auto add = [](V a, V b) { return V{a.x + b.x, a.y + b.y, a.z + b.z}; };
+	auto scl = [](double s, V a) { return V{s * a.x, s * a.y, s * a.z}; };
+	auto dotp = [](V a, V b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); };
+	auto divs = [](V a, double c) { return V{a.x / c, a.y / c, a.z / c}; };
+	auto l2 = [](V a) { return a.x * a.x + a.y * a.y + a.z * a.z; };
+	auto cross = [](V a, V b) { return V{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+	auto unitv = [&](V a) { double d = l2(a); return d > 0.0 ? divs(a, std::sqrt(d)) : V{0, 0, 0}; };
+	const V E{eye[0], eye[1], eye[2]}, L{lookat[0], lookat[1], lookat[2]}, Up{up[0], up[1], up[2]};
+	double width = x_win[1] - x_win[0], height = y_win[1] - y_win[0]; // interval.h:15-20
+	if (!(width > 0.0)) width = 0.0;
+	if (!(height > 0.0)) height = 0.0;
+	const V G = unitv(sub(L, E));
+	V upG = Up; // vec3.h:70-75, operator/(Vec3,Vec3): remove the component parallel to G
+	{
+		double x = l2(G);
+		if (x > 0.0) upG = sub(Up, scl(dotp(Up, G) / x, G));
+	}
+	const V U = unitv(upG);
+	const V R = unitv(cross(G, U));
+	const V O = add(add(scl(vpdist, G), scl(x_win[0], R)), scl(y_win[1], U));
+	const V dR = divs(scl(width, R), (double)x_res);
+	const V dU = divs(scl(height, U), (double)y_res);
+	out->eye[0] = E.x; out->eye[1] = E.y; out->eye[2] = E.z;
+	out->O[0] = O.x; out->O[1] = O.y; out->O[2] = O.z;
+	out->dR[0] = dR.x; out->dR[1] = dR.y; out->dR[2] = dR.z;
+	out->dU[0] = dU.x; out->dU[1] = dU.y; out->dU[2] = dU.z;
+	out->x_res = x_res;
+	out->y_res = y_res;
+	return 0;
+}
+
+int rtmi_primary_closest_hit_dev(rtmi_scene *s, const rtmi_camera *cam, double sx, double sy, uint32_t tile_w,
+                                 uint32_t tile_h, uint32_t tile_first, uint32_t tile_stride, rtmi_hit *d_out,
+                                 void *stream) {
+	const char *who = "rtmi_primary_closest_hit_dev";
+	if (check_scene(s, who)) return -1;
+	if (!cam || !d_out) return fail(std::string(who) + ": NULL argument");
+	if (cam->x_res == 0 || cam->y_res == 0) return fail(std::string(who) + ": zero resolution");
+	if (tile_w == 0 || tile_h == 0) { tile_w = cam->x_res; tile_h = cam->y_res; }
+	if (tile_stride == 0) return fail(std::string(who) + ": tile_stride must be >= 1");
+	const uint32_t tiles_x = (cam->x_res + tile_w - 1) / tile_w, tiles_y = (cam->y_res + tile_h - 1) / tile_h;
+	const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
+	if (tile_first >= n_tiles) return 0;
+	const uint64_t local = (n_tiles - tile_first + tile_stride - 1) / tile_stride;
+	const uint32_t bx = (tile_w + 15) / 16, by = (tile_h + 15) / 16;
+	const uint64_t grid = local * bx * by;
+	if (grid > 0x7fffffffull) return fail(std::string(who) + ": grid too large");
+	hipLaunchKernelGGL(k_primary_closest, dim3((uint32_t)grid), dim3(kBlock), 0, (hipStream_t)stream, s->dev, *cam, sx, sy,
+	                   tile_w, tile_h, tiles_x, tile_first, tile_stride, bx, bx * by, d_out);
+	return launch_check(who);
+}
+
+int rtmi_primary_rays_dev(const rtmi_camera *cam, double sx, double sy, rtmi_ray *d_rays, void *stream) {
+	if (!cam || !d_rays) return fail("rtmi_primary_rays_dev: NULL argument");
+	const uint64_t n = (uint64_t)cam->x_res * cam->y_res;
+	if (n == 0) return 0;
+	hipLaunchKernelGGL(k_primary_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *cam, sx, sy, d_rays);
+	return launch_check("rtmi_primary_rays_dev");
+}
+
+} // extern "C"
