@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path on BASELINE.json's metric: "closest-hit Mrays/s on 1M-tri scene; form-factor+solve
+time @64K patches".
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the closest-hit path over one batch of synthetic primary rays: the 3840x2160 frame of
+the 1 Mi-triangle soup, rays generated on the device, hit records written to HBM.  With N
+ranks the job is N samples per pixel of that frame (weak scaling: 8 294 400 rays per GPU per step); every
+sample's 64x64 image tiles are dealt round-robin over the ranks, no collective on the data path.
+`value` = rays of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+  roofline            the Jacobi sweep (the HBM-bound kernel of the metric's second half), 4·n_rows·n bytes/launch
+  roofline_traversal  the closest-hit kernel (VALU/L2-latency bound, neither "hbm" nor "mfma": SURVEY.md §8d)
+  solver / formfactor the 64 K-patch solve (synthetic F, row-sharded over the ranks) and form-factor build rate
+  cpu_baseline        the oracle (CPU restatement, OpenMP) on a bounded sample of the same rays, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
+# algorithmic work per traversal event: one node visit = two fp32 slab tests,
+# one triangle test = the reference's Möller–Trumbore in fp64 (priced at 2 fp32-equivalents per flop)
+FLOP_NODE_VISIT = 46.0
+FLOP_TRI_TEST = 46.0 * 2.0
+BYTES_NODE, BYTES_TRI, BYTES_HIT = 64.0, 80.0, 24.0
+
+
+def halton(i, b):
+    f, r = 1.0, 0.0
+    while i > 0:
+        f /= b
+        r += f * (i % b)
+        i //= b
+    return r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tris", type=int, default=1 << 20)
+    ap.add_argument("--res", default="3840x2160")
+    ap.add_argument("--patches", type=int, default=65536)
+    ap.add_argument("--ff-rows", type=int, default=128, help="rows of the 64K-patch form-factor matrix to build (sample)")
+    ap.add_argument("--no-solver", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-row-stride", type=int, default=2)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    from raytracer_amd import multi, workloads
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ------------------------------------------------------------------ closest hit, C3
+    x_res, y_res = (int(v) for v in args.res.lower().split("x"))
+    tris = workloads.soup(args.tris, seed=1)
+    scene = rt.Scene(tris)                      # host BVH build + upload, replicated per rank; not timed
+    info = scene.info()
+    cam = rt.Camera.from_cam14(workloads.SOUP_CAM14, (x_res, y_res))
+    n_pix = x_res * y_res
+    spp = world
+    offs = [(0.5, 0.5)] + [(halton(s, 2), halton(s, 3)) for s in range(1, spp)]
+    TILE = (64, 64)
+    frames = [torch.empty(n_pix * rt.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(spp)]
+    rays_rank = sum(multi.pixels_of_rank(x_res, y_res, TILE[0], TILE[1], (rank + s) % world, world) for s in range(spp))
+    rays_total = spp * n_pix
+
+    def step():
+        for s in range(spp):
+            scene.primary_dev(cam, frames[s].data_ptr(), sx=offs[s][0], sy=offs[s][1], tile=TILE,
+                              tile_first=(rank + s) % world, tile_stride=world, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step()
+        ev[k][1].record()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * spp)      # average duration of one launch
+    mrays = rays_total * args.steps / dt / 1e6
+
+    # traversal work of the frame (diagnostic kernel, untimed) -> roofline of the closest-hit kernel
+    counts = torch.zeros(2, dtype=torch.int64, device="cuda")
+    scene.primary_work_dev(cam, counts.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    visits, tests = (int(v) for v in counts.cpu())
+    flop_per_ray = (visits * FLOP_NODE_VISIT + tests * FLOP_TRI_TEST) / n_pix
+    l2_bytes_per_ray = (visits * BYTES_NODE + tests * BYTES_TRI) / n_pix + BYTES_HIT
+    rays_per_launch = rays_rank / spp
+    trav_tflops = flop_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e12
+    roofline_traversal = {
+        "kernel": "k_primary_closest", "bound": "valu", "achieved": round(trav_tflops, 3), "peak": FP32_PEAK_TFLOPS,
+        "unit": "TFLOP/s (fp32-equivalent; fp64 flop = 2)", "frac": round(trav_tflops / FP32_PEAK_TFLOPS, 4),
+        "kernel_ms": round(kernel_ms, 4), "rays_per_launch": int(rays_per_launch),
+        "node_visits_per_ray": round(visits / n_pix, 2), "tri_tests_per_ray": round(tests / n_pix, 2),
+        "l2_bytes_per_ray": round(l2_bytes_per_ray, 1),
+        "l2_gbs": round(l2_bytes_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e9, 1), "traffic": None,
+    }
+
+    # ------------------------------------------------------------------ radiosity solve, C5 (synthetic F)
+    solver = None
+    roofline = None
+    formfactor = None
+    if not args.no_solver:
+        n = args.patches
+        row0, n_rows, _ = multi.rows_of_rank(n, rank, world)
+        ld = (n + 3) // 4 * 4
+        F = workloads.synthetic_F(n, n_rows=n_rows, row0=row0, seed=1, ld=ld)
+        rho = np.array([0.7, 0.7, 0.7])
+        E_h = np.zeros((n, 3), np.float32)
+        E_h[::97] = 68500.0 / 97.0
+        E_h[n - 1] = 68500.0
+        E = torch.from_numpy(E_h).cuda()
+
+        def sweep(B_old, B_new, norms):
+            rt.jacobi_sweep_dev(F.data_ptr(), ld, n, row0, n_rows, rho, E.data_ptr(), B_old.data_ptr(), B_new.data_ptr(),
+                                norms.data_ptr(), stream)
+
+        # (a) the kernel alone: K sweeps back to back, HIP events on the launch stream
+        Ba = E.clone(); Bb = torch.zeros_like(Ba)
+        norms = torch.zeros(3, dtype=torch.float64, device="cuda")
+        for _ in range(3):
+            sweep(Ba, Bb, norms)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_sw = max(10, args.steps)
+        barrier()
+        e0.record()
+        for _ in range(n_sw // 2):
+            sweep(Ba, Bb, norms)
+            sweep(Bb, Ba, norms)
+        e1.record()
+        torch.cuda.synchronize()
+        sweep_ms = e0.elapsed_time(e1) / (2 * (n_sw // 2))
+        bytes_launch = 4.0 * n_rows * n
+        gbs = bytes_launch / (sweep_ms * 1e-3) / 1e9
+        roofline = {"kernel": "k_jacobi_sweep", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": bytes_launch, "kernel_ms": round(sweep_ms, 4)}
+        tr = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, measured separately
+        if os.path.exists(tr):
+            try:
+                tj = json.load(open(tr))
+                if tj.get("k_jacobi_sweep", {}).get("bytes_per_launch") == bytes_launch:
+                    roofline["traffic"] = tj["k_jacobi_sweep"]["hbm_bytes"]
+                if tj.get("k_primary_closest", {}).get("rays_per_launch") == int(rays_per_launch):
+                    roofline_traversal["traffic"] = tj["k_primary_closest"]["hbm_bytes"]
+            except Exception:
+                pass
+        # (b) the whole solve to 1e-4 relative change (north star), exchange included when N > 1
+        barrier()
+        t0 = time.perf_counter()
+        if world == 1:
+            B = torch.zeros_like(E)
+            stats = rt.api.rtmi_solve_stats()
+            rc = rt.lib.rtmi_radiosity_solve_dev(F.data_ptr(), ld, n, 0, n, rho.ctypes.data, E.data_ptr(), B.data_ptr(), 1e-4,
+                                                 1000, 4, None, None, rt.api.C.byref(stats), stream)
+            if rc != 0:
+                raise SystemExit(rt.lib.rtmi_last_error().decode())
+            sweeps, rel = stats.sweeps, stats.rel_change
+        else:
+            r = multi.solve_sharded(sweep, E, n, tol_rel=1e-4, max_sweeps=1000, check_every=4)
+            B, sweeps, rel = r.B, r.sweeps, r.rel_change
+        barrier()
+        solve_s = max_over_ranks(time.perf_counter() - t0)
+        # residual of the solution: one more sweep must not move it
+        norms.zero_()
+        Bc = torch.zeros((B.shape[0], 3), dtype=torch.float32, device="cuda")
+        sweep(B.contiguous(), Bc, norms)
+        torch.cuda.synchronize()
+        solver = {"patches": n, "F": "synthetic uniform(0,1), zero diagonal, row sums 0.9, fp32, %.2f GiB/rank" % (n_rows * ld * 4 / 2**30),
+                  "scaling": "strong (rows sharded over ranks, RCCL all-gather of B per sweep)" if world > 1 else "single GPU",
+                  "sweeps": int(sweeps), "rel_change": rel, "solve_seconds": round(solve_s, 5),
+                  "ms_per_sweep_kernel": round(sweep_ms, 4), "ms_per_sweep_in_solve": round(solve_s * 1e3 / max(1, sweeps), 4)}
+        del F
+        torch.cuda.empty_cache()
+
+        # (c) form-factor build rate at 64 K patches: closed box with 12·74² = 65 712 patches, a sample of rows
+        if args.ff_rows > 0:
+            k = max(1, int(round((n / 12.0) ** 0.5)))
+            verts, normals, light = workloads.closed_box(k)
+            box = rt.Scene(verts)
+            rad = rt.Radiosity(box, normals, light)
+            r0, nr, _ = multi.rows_of_rank(rad.n, rank, world)
+            nr_s = min(args.ff_rows, nr)
+            rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=r0, n_rows=min(8, nr_s))   # warm-up
+            barrier()
+            t0 = time.perf_counter()
+            rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=r0, n_rows=nr_s)
+            barrier()
+            ff_s = max_over_ranks(time.perf_counter() - t0)
+            vis_rays = 10.0 * nr_s * (rad.n - 2) * world
+            formfactor = {"patches": rad.numOfElements, "rows_built_per_rank": nr_s, "seconds": round(ff_s, 4),
+                          "visibility_Mrays_per_s": round(vis_rays / ff_s / 1e6, 1),
+                          "extrapolated_full_build_seconds": round(ff_s * nr / nr_s, 1),
+                          "note": "sample of rows; every row costs the same number of visibility rays"}
+            rad.close(); box.close()
+
+    # ------------------------------------------------------------------ CPU baseline (oracle), rank 0, N = 1
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle_py import Oracle
+        ora = Oracle()
+        rows = np.arange(0, y_res, max(1, args.cpu_row_stride), dtype=np.uint32)
+        ii, jj = np.meshgrid(rows, np.arange(x_res, dtype=np.uint32), indexing="ij")
+        pix = np.stack([ii.ravel(), jj.ravel()], 1)
+        d = ora.primary_dirs(ora.raster_details(workloads.SOUP_CAM14, x_res, y_res), pix)
+        o = np.tile(workloads.SOUP_CAM14[:3], (len(d), 1))
+        h = ora.bvh_build(tris)
+        (tri, t, u, v), secs = ora.bvh_closest_hit(h, o, d)
+        ora.bvh_free(h)
+        got = frames[0].cpu().numpy().view(rt.HIT_DTYPE)[pix[:, 0].astype(np.int64) * x_res + pix[:, 1]]
+        mism = int((got["tri"] != np.where(tri < 0, rt.MISS, tri).astype(np.uint32)).sum() + (got["t"] != t).sum())
+        cpu = {"value": round(len(d) / secs / 1e6, 3), "unit": "Mrays/s", "cores": ora.num_threads(), "kind": "port",
+               "sample": "rows 0,%d,.. of the %dx%d frame: %d of the step's rays, oracle BVH + the reference's double Moller-Trumbore, %.1f s" % (
+                   args.cpu_row_stride, x_res, y_res, len(d), secs),
+               "gpu_vs_oracle_mismatches_on_sample": mism}
+
+    if rank == 0:
+        line = {
+            "metric": "closest-hit Mrays/s on 1M-tri scene; form-factor+solve time @64K patches",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 (triangle test) + f32 (box tests)", "data": "synthetic",
+            "config": {"workload": "C3: %d-triangle random soup, %dx%d primary rays x %d spp (1 spp per GPU), closest hit" % (
+                           args.tris, x_res, y_res, spp),
+                       "rays_per_step": rays_total, "tiles": "%dx%d round-robin over ranks" % TILE,
+                       "bvh": {"nodes": int(info.n_nodes), "leaves": int(info.n_leaves), "depth": int(info.max_depth),
+                               "max_leaf": int(info.max_leaf_size), "build_seconds": round(info.build_seconds, 2),
+                               "device_MB": round(info.device_bytes / 1e6, 1)}},
+            "roofline": roofline, "roofline_traversal": roofline_traversal, "solver": solver, "formfactor": formfactor,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,14 @@ typedef struct rtmi_scene_info {
 const char *rtmi_last_error(void);
 int rtmi_device_count(void);
 
+/* ---- the triangle test on its own ------------------------------------------------------------------
+ * Replaces double triangle_intersection(orig, dir, v0, v1, v2, planeNormal, u, v)
+ * (Render2/object.cpp:29-60, external linkage) on n independent pairs, host pointers:
+ * o, d: n × 3; tri: n × 9 (v0, v1, v2); t[k] = 0.0 means miss; u, v are in/out and are written only
+ * as far as the reference writes them before each early return. */
+int rtmi_triangle_intersection(uint64_t n, const double *o, const double *d, const double *tri, double *t, double *u,
+                               double *v);
+
 /* ---- acceleration structure -------------------------------------------------------------------
  * Replaces Scene::BuildBSP (Render2/scene.cpp:463-479, 528-693).  tri_xyz: n_tris × 9 doubles
  * (triVert1, triVert2, triVert3) in Scene::sceneObjects / Object::triangles order — that order IS
@@ -99,6 +107,10 @@ int rtmi_primary_closest_hit_dev(rtmi_scene *, const rtmi_camera *cam, double sx
                                  uint32_t tile_h, uint32_t tile_first, uint32_t tile_stride, rtmi_hit *d_out,
                                  void *stream);
 int rtmi_primary_rays_dev(const rtmi_camera *cam, double sx, double sy, rtmi_ray *d_rays, void *stream);
+/* Diagnostic (no counterpart in the reference): the traversal work of the same frame of primary rays,
+ * ADDED to d_counts[0] (node visits, two child boxes each) and d_counts[1] (exact triangle tests).
+ * bench.py prices the traversal kernel's roofline with it. */
+int rtmi_primary_work_dev(rtmi_scene *, const rtmi_camera *cam, double sx, double sy, uint64_t *d_counts, void *stream);
 
 /* ---- any hit --------------------------------------------------------------------------------------
  * Replaces Scene::Cast used as a predicate: shadows (Render2/shader.cpp:131, tmax = 1e20), ambient
@@ -140,7 +152,8 @@ int rtmi_form_factors_dev(rtmi_patches *, const double *light_center, uint32_t s
  * F fp32 (streamed from HBM once per sweep), B/E fp32 [n][3], accumulation in double.
  * One call = one sweep over rows [row0, row0+n_rows): reads d_B_old (all n), writes
  * d_B_new[row0..row0+n_rows) (same [n][3] indexing) and ADDS to d_norms[0] += Σ(B_new−B_old)²,
- * d_norms[1] += ΣB_new², d_norms[2] = max(d_norms[2], max|B_new−B_old|) over its rows
+ * d_norms[1] += Σ(B_new−E)² (the gathered part ρ·F·B: an emitter's own power — the light's 68 500 —
+ * must not set the scale), d_norms[2] = max(d_norms[2], max|B_new−B_old|) over its rows
  * (the caller zeroes d_norms; [2] is the reference's stop quantity, :478).
  * Multi-GPU: rows shard; the caller all-gathers d_B_new between sweeps (RCCL). */
 int rtmi_jacobi_sweep_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows,
@@ -149,7 +162,7 @@ int rtmi_jacobi_sweep_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t ro
 
 typedef struct rtmi_solve_stats {
 	uint32_t sweeps;
-	double rel_change; /* ‖B_k − B_{k-1}‖₂ / ‖B_k‖₂ at exit */
+	double rel_change; /* ‖B_k − B_{k-1}‖₂ / ‖B_k − E‖₂ at exit */
 	double max_change; /* max_i |B_k − B_{k-1}| at exit = max residual of B_{k-1} */
 	double seconds;    /* device time of the sweeps (HIP events) */
 	double bytes_per_sweep;

@@ -54,9 +54,9 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_
 
 # every symbol include/rtmi.h declares (tests check the library exports exactly these)
 SYMBOLS = [
-    "rtmi_last_error", "rtmi_device_count", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_get_info",
+    "rtmi_last_error", "rtmi_device_count", "rtmi_triangle_intersection", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_get_info",
     "rtmi_closest_hit", "rtmi_closest_hit_dev", "rtmi_camera_setup", "rtmi_primary_closest_hit_dev",
-    "rtmi_primary_rays_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
+    "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev",
 ]
 
@@ -68,6 +68,7 @@ def _load():
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_double
     L.rtmi_last_error.restype = C.c_char_p
+    L.rtmi_triangle_intersection.argtypes = [u64, vp, vp, vp, vp, vp, vp]
     L.rtmi_scene_create.restype = vp
     L.rtmi_scene_create.argtypes = [vp, vp, u64]
     L.rtmi_scene_destroy.argtypes = [vp]
@@ -80,6 +81,7 @@ def _load():
     L.rtmi_camera_setup.argtypes = [vp, vp, vp, dbl, vp, vp, u32, u32, C.POINTER(rtmi_camera)]
     L.rtmi_primary_closest_hit_dev.argtypes = [vp, C.POINTER(rtmi_camera), dbl, dbl, u32, u32, u32, u32, vp, vp]
     L.rtmi_primary_rays_dev.argtypes = [C.POINTER(rtmi_camera), dbl, dbl, vp, vp]
+    L.rtmi_primary_work_dev.argtypes = [vp, C.POINTER(rtmi_camera), dbl, dbl, vp, vp]
     L.rtmi_patches_create.restype = vp
     L.rtmi_patches_create.argtypes = [vp, vp, vp]
     L.rtmi_patches_destroy.argtypes = [vp]
@@ -120,6 +122,17 @@ def make_rays(o, d, tmax=None):
     r["o"] = o; r["d"] = d
     r["tmax"] = INFINITY if tmax is None else tmax
     return r
+
+
+def triangle_intersection(o, d, v0, v1, v2, u0=0.0, v0_=0.0):
+    """triangle_intersection (object.cpp:29-60) on a batch; returns (t, u, v), t == 0.0 is a miss."""
+    o = _np(o, np.float64, (-1, 3)); d = _np(d, np.float64, (-1, 3))
+    tri = np.ascontiguousarray(np.concatenate([_np(v0, np.float64, (-1, 3)), _np(v1, np.float64, (-1, 3)),
+                                               _np(v2, np.float64, (-1, 3))], axis=1))
+    n = len(o)
+    t = np.zeros(n); u = np.full(n, float(u0)); v = np.full(n, float(v0_))
+    _check(lib.rtmi_triangle_intersection(n, _ptr(o), _ptr(d), _ptr(tri), _ptr(t), _ptr(u), _ptr(v)))
+    return t, u, v
 
 
 class Camera:
@@ -212,6 +225,11 @@ class Scene:
                                                 tile_stride, d_out, stream))
 
 
+    def primary_work_dev(self, cam, d_counts, sx=0.5, sy=0.5, stream=0):
+        """Diagnostic: adds (node visits, triangle tests) of the frame's primary rays to d_counts[0..1] (uint64)."""
+        _check(lib.rtmi_primary_work_dev(self.handle, C.byref(cam.c), sx, sy, d_counts, stream))
+
+
 def primary_rays_dev(cam, d_rays, sx=0.5, sy=0.5, stream=0):
     _check(lib.rtmi_primary_rays_dev(C.byref(cam.c), sx, sy, d_rays, stream))
 
@@ -274,22 +292,36 @@ class Radiosity:
             E[self.n - 1] = self.SOLAR_RADIOSITY_POWER
         return E
 
-    def progressiveRefinement(self, rho=None, E=None, tol_rel=1e-7, max_sweeps=1000, check_every=4, exchange=None):
-        """Solves (I − ρF)·B = E — the system radiosity.cpp:483-563 iterates on — by Jacobi sweeps on the GPU."""
+    def progressiveRefinement(self, rho=None, E=None, tol_rel=1e-7, max_sweeps=1000, check_every=4):
+        """Solves (I − ρF)·B = E — the system radiosity.cpp:483-563 iterates on — by Jacobi sweeps on the GPU.
+        With torch.distributed initialised (one process per GPU) FF holds this rank's rows and the ranks
+        all-gather B after every sweep (multi.solve_sharded); otherwise the whole loop runs inside the library."""
         import torch
+        import torch.distributed as dist
         rho = _np([self.REFLECTIVITY_INDEX] * 3 if rho is None else rho, np.float64, (3,))
         E = self.emission() if E is None else _np(E, np.float32, (self.n, 3))
         dE = torch.from_numpy(E).cuda()
-        dB = torch.zeros_like(dE)
-        stats = rtmi_solve_stats()
-        cb = EXCHANGE_FN(exchange) if exchange is not None else None
         st = torch.cuda.current_stream().cuda_stream
-        _check(lib.rtmi_radiosity_solve_dev(self.FF.data_ptr(), self.ld, self.n, self.row0, self.n_rows, _ptr(rho),
-                                            dE.data_ptr(), dB.data_ptr(), tol_rel, max_sweeps, check_every,
-                                            C.cast(cb, C.c_void_p) if cb else None, None, C.byref(stats), st))
-        self.B = dB
+        stats = rtmi_solve_stats()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from . import multi
+            row0, n_rows = self.row0, self.n_rows
+
+            def sweep(B_old, B_new, norms):
+                jacobi_sweep_dev(self.FF.data_ptr(), self.ld, self.n, row0, n_rows, rho, dE.data_ptr(), B_old.data_ptr(),
+                                 B_new.data_ptr(), norms.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            r = multi.solve_sharded(sweep, dE, self.n, tol_rel, max_sweeps, check_every)
+            self.B = r.B
+            stats.sweeps, stats.rel_change, stats.max_change = r.sweeps, r.rel_change, r.max_change
+            stats.bytes_per_sweep = 4.0 * n_rows * self.n
+        else:
+            dB = torch.zeros_like(dE)
+            _check(lib.rtmi_radiosity_solve_dev(self.FF.data_ptr(), self.ld, self.n, self.row0, self.n_rows, _ptr(rho),
+                                                dE.data_ptr(), dB.data_ptr(), tol_rel, max_sweeps, check_every,
+                                                None, None, C.byref(stats), st))
+            self.B = dB
         self.stats = stats
-        return dB
+        return self.B
 
     def setRadiosityForAllElements(self):
         """radiosity.cpp:122-134: QuadTreeNode::radiosityValue[i] = B[i] (monochrome = channel 0), as doubles."""

@@ -121,9 +121,12 @@ __device__ __forceinline__ float f32_above(double x) { return __double2float_ru(
 // ANY = false: closest hit — strict minimum of the positive t below tmax; equal t -> smaller
 //              original id (the in-order scan of Render2/object.cpp:143-168 keeps the first).
 // ANY = true : stop at the first triangle with 0 < t < tmax (Render2/shader.cpp:131,226).
-template <bool ANY>
+// COUNT = true additionally tallies node visits and triangle tests (the roofline's work count).
+struct Work { uint32_t nodes, tests; };
+
+template <bool ANY, bool COUNT = false>
 __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, double oz, double dx, double dy,
-                                      double dz, double tmax, int *stack, Hit &h) {
+                                      double dz, double tmax, int *stack, Hit &h, Work *w = nullptr) {
 	h.t = 0.0; h.u = 0.0; h.v = 0.0;
 	h.orig = RTMI_MISS; h.object = RTMI_MISS; h.pos = RTMI_MISS;
 	double best = tmax;
@@ -134,6 +137,7 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 	while (cur != kSentinel) {
 		if (cur >= 0) {
 			const GNode *np = S.nodes + cur;
+			if (COUNT) ++w->nodes;
 			const float4 a = np->a, b = np->b, c = np->c;
 			const int4 d = np->d;
 			float t0, t1;
@@ -160,6 +164,7 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 			bool done = false;
 			for (uint32_t k = first; k < first + cnt; ++k) {
 				const GTri &T = S.tris[k];
+				if (COUNT) ++w->tests;
 				double u = 0.0, v = 0.0;
 				const double t = mt_exact(ox, oy, oz, dx, dy, dz, T, u, v);
 				if (ANY) {

@@ -204,11 +204,12 @@ __global__ __launch_bounds__(kBlock) void k_jacobi_sweep(const float *__restrict
 			const double s = red[0][r][ch] + red[1][r][ch] + red[2][r][ch] + red[3][r][ch];
 			const size_t gi = 3 * (size_t)(row0 + r0 + r) + ch;
 			const double rho = ch == 0 ? rho0 : (ch == 1 ? rho1 : rho2);
-			const float bn = (float)((double)E[gi] + rho * s);
+			const double e = (double)E[gi];
+			const float bn = (float)(e + rho * s);
 			const double d = (double)bn - (double)Bold[gi];
 			Bnew[gi] = bn;
 			d2 = d * d;
-			b2 = (double)bn * (double)bn;
+			b2 = ((double)bn - e) * ((double)bn - e);
 			dmax = fabs(d);
 		}
 #pragma unroll

@@ -71,6 +71,32 @@ __global__ __launch_bounds__(kBlock) void k_primary_closest(SceneDev S, rtmi_cam
 	out[(uint64_t)i * cam.x_res + j] = o;
 }
 
+// Same rays as k_primary_closest (all tiles); only counts the traversal work: counts[0] += node visits
+// (one visit = two child boxes), counts[1] += exact triangle tests.  Diagnostic, not on the hot path.
+__global__ __launch_bounds__(kBlock) void k_primary_work(SceneDev S, rtmi_camera cam, double sx, double sy,
+                                                         unsigned long long *__restrict__ counts) {
+	__shared__ int stack[kStackDepth * kBlock];
+	const uint32_t bx = (cam.x_res + 15) / 16;
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const uint32_t j = (blockIdx.x % bx) * 16 + (wave & 1) * 8 + (lane & 7);
+	const uint32_t i = (blockIdx.x / bx) * 16 + (wave >> 1) * 8 + (lane >> 3);
+	Work w = {0u, 0u};
+	if (j < cam.x_res && i < cam.y_res) {
+		const D3 d = primary_dir(cam, i, j, sx, sy);
+		Hit h;
+		trace<false, true>(S, cam.eye[0], cam.eye[1], cam.eye[2], d.x, d.y, d.z, RTMI_INFINITY, stack + threadIdx.x, h, &w);
+	}
+	unsigned long long a = w.nodes, b = w.tests;
+	for (int off = 32; off > 0; off >>= 1) {
+		a += __shfl_xor(a, off, 64);
+		b += __shfl_xor(b, off, 64);
+	}
+	if (lane == 0) {
+		atomicAdd(&counts[0], a);
+		atomicAdd(&counts[1], b);
+	}
+}
+
 __global__ void k_primary_rays(rtmi_camera cam, double sx, double sy, rtmi_ray *__restrict__ rays) {
 	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t n = (uint64_t)cam.x_res * cam.y_res;
@@ -83,6 +109,24 @@ __global__ void k_primary_rays(rtmi_camera cam, double sx, double sy, rtmi_ray *
 	R.tmax = RTMI_INFINITY;
 	R.reserved = 0.0;
 	rays[k] = R;
+}
+
+// Render2/object.cpp:29-60 on n independent (ray, triangle) pairs: the known-answer entry point.
+__global__ void k_triangle_intersection(uint64_t n, const double *__restrict__ o, const double *__restrict__ d,
+                                        const double *__restrict__ tri, double *__restrict__ t, double *__restrict__ u,
+                                        double *__restrict__ v) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	GTri T;
+	for (int a = 0; a < 3; ++a) {
+		T.v0[a] = tri[9 * k + a];
+		T.e1[a] = tri[9 * k + 3 + a] - tri[9 * k + a];
+		T.e2[a] = tri[9 * k + 6 + a] - tri[9 * k + a];
+	}
+	double uu = u[k], vv = v[k]; // the reference leaves u, v untouched on the early exits
+	t[k] = mt_exact(o[3 * k], o[3 * k + 1], o[3 * k + 2], d[3 * k], d[3 * k + 1], d[3 * k + 2], T, uu, vv);
+	u[k] = uu;
+	v[k] = vv;
 }
 
 // ------------------------------------------------------------------------------------------- scene
@@ -282,6 +326,34 @@ int rtmi_any_hit_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, uint8_t 
 	return trace_dev<true>(s, d_rays, n, nullptr, d_occluded, stream, "rtmi_any_hit_dev");
 }
 
+int rtmi_triangle_intersection(uint64_t n, const double *o, const double *d, const double *tri, double *t, double *u,
+                               double *v) {
+	const char *who = "rtmi_triangle_intersection";
+	if (n == 0) return 0;
+	if (!o || !d || !tri || !t || !u || !v) return fail(std::string(who) + ": NULL buffer");
+	if (n > (uint64_t)0x7fffffff * 256) return fail(std::string(who) + ": too many pairs for one launch");
+	double *buf = nullptr; // o[3n] d[3n] tri[9n] t[n] u[n] v[n]
+	if (hipMalloc(&buf, sizeof(double) * 18 * n) != hipSuccess) return fail(std::string(who) + ": hipMalloc failed");
+	double *d_o = buf, *d_d = buf + 3 * n, *d_tri = buf + 6 * n, *d_t = buf + 15 * n, *d_u = buf + 16 * n, *d_v = buf + 17 * n;
+	bool ok = hipMemcpy(d_o, o, 24 * n, hipMemcpyHostToDevice) == hipSuccess &&
+	          hipMemcpy(d_d, d, 24 * n, hipMemcpyHostToDevice) == hipSuccess &&
+	          hipMemcpy(d_tri, tri, 72 * n, hipMemcpyHostToDevice) == hipSuccess &&
+	          hipMemcpy(d_u, u, 8 * n, hipMemcpyHostToDevice) == hipSuccess &&
+	          hipMemcpy(d_v, v, 8 * n, hipMemcpyHostToDevice) == hipSuccess;
+	int rc = ok ? 0 : fail(std::string(who) + ": H2D copy failed");
+	if (!rc) {
+		hipLaunchKernelGGL(k_triangle_intersection, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, nullptr, n, d_o, d_d, d_tri,
+		                   d_t, d_u, d_v);
+		rc = launch_check(who);
+	}
+	if (!rc && (hipMemcpy(t, d_t, 8 * n, hipMemcpyDeviceToHost) != hipSuccess ||
+	            hipMemcpy(u, d_u, 8 * n, hipMemcpyDeviceToHost) != hipSuccess ||
+	            hipMemcpy(v, d_v, 8 * n, hipMemcpyDeviceToHost) != hipSuccess))
+		rc = fail(std::string(who) + ": D2H copy failed: " + hipGetErrorString(hipGetLastError()));
+	(void)hipFree(buf);
+	return rc;
+}
+
 // Render2/rasterizer.cpp:40-56 with the reference's Vec3 operators (vec3.h) restated on the host.
 int rtmi_camera_setup(const double eye[3], const double lookat[3], const double up[3], double vpdist,
                       const double x_win[2], const double y_win[2], uint32_t x_res, uint32_t y_res, rtmi_camera *out) {
@@ -338,6 +410,18 @@ int rtmi_primary_closest_hit_dev(rtmi_scene *s, const rtmi_camera *cam, double s
 	if (grid > 0x7fffffffull) return fail(std::string(who) + ": grid too large");
 	hipLaunchKernelGGL(k_primary_closest, dim3((uint32_t)grid), dim3(kBlock), 0, (hipStream_t)stream, s->dev, *cam, sx, sy,
 	                   tile_w, tile_h, tiles_x, tile_first, tile_stride, bx, bx * by, d_out);
+	return launch_check(who);
+}
+
+int rtmi_primary_work_dev(rtmi_scene *s, const rtmi_camera *cam, double sx, double sy, uint64_t *d_counts, void *stream) {
+	const char *who = "rtmi_primary_work_dev";
+	if (check_scene(s, who)) return -1;
+	if (!cam || !d_counts) return fail(std::string(who) + ": NULL argument");
+	if (cam->x_res == 0 || cam->y_res == 0) return fail(std::string(who) + ": zero resolution");
+	const uint64_t grid = (uint64_t)((cam->x_res + 15) / 16) * ((cam->y_res + 15) / 16);
+	if (grid > 0x7fffffffull) return fail(std::string(who) + ": grid too large");
+	hipLaunchKernelGGL(k_primary_work, dim3((uint32_t)grid), dim3(kBlock), 0, (hipStream_t)stream, s->dev, *cam, sx, sy,
+	                   (unsigned long long *)d_counts);
 	return launch_check(who);
 }
 

@@ -1,0 +1,76 @@
+"""Synthetic inputs for the configurations BASELINE.json names.  Host-side numpy only:
+these produce the arrays a host driver would hand to the C ABI; nothing here computes a result.
+
+    soup(n)            C3: n random small triangles in [-1,1]^3, camera looking down +z at 3840x2160
+    closed_box(k)      C2/C5: 6 walls of k x k x 2 triangles each, normals inward, side 10, + light centre
+    synthetic_F(...)   C5 (solver only): device-resident fp32 matrix, zero diagonal, rows scaled to sum 0.9
+"""
+import numpy as np
+
+# C3 camera: eye, lookat, up, vpdist, x_win, y_win (the 14 numbers of Render2/ray_tracer.h:113-122)
+SOUP_CAM14 = np.array([0, 0, -3, 0, 0, 0, 0, 1, 0, 2.75, -1.6, 1.6, -0.9, 0.9], np.float64)
+SOUP_RES = (3840, 2160)
+
+
+def soup(n_tris=1 << 20, seed=1, edge=0.01):
+    """n_tris x 9 doubles: centres uniform in [-1,1]^3, the two edge vectors uniform in [-edge,edge]^3."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.uniform(-1.0, 1.0, (n_tris, 3))
+    e1 = rng.uniform(-edge, edge, (n_tris, 3))
+    e2 = rng.uniform(-edge, edge, (n_tris, 3))
+    return np.concatenate([c, c + e1, c + e2], axis=1)
+
+
+def closed_box(k, side=10.0):
+    """Cornell-type closed box: returns (verts n x 9, normals n x 3 pointing inward, light centre).
+    n = 12 k^2.  Wall order: z=0, z=side, y=0, y=side, x=0, x=side; rows of quads, 2 triangles per quad."""
+    h = side / k
+    g = np.arange(k) * h
+    a, b = np.meshgrid(g, g, indexing="ij")
+    a = a.ravel(); b = b.ravel()
+    verts, normals = [], []
+    for axis in range(3):
+        for far in (0, 1):
+            w = side if far else 0.0
+            ua, ub = [(1, 2), (0, 2), (0, 1)][axis]
+
+            def P(da, db):
+                p = np.zeros((len(a), 3))
+                p[:, axis] = w
+                p[:, ua] = a + da
+                p[:, ub] = b + db
+                return p
+            p00, p10, p11, p01 = P(0, 0), P(h, 0), P(h, h), P(0, h)
+            t1 = np.concatenate([p00, p10, p11], 1)
+            t2 = np.concatenate([p00, p11, p01], 1)
+            t = np.stack([t1, t2], 1).reshape(-1, 9)
+            nrm = np.zeros(3)
+            nrm[axis] = -1.0 if far else 1.0
+            verts.append(t)
+            normals.append(np.tile(nrm, (len(t), 1)))
+    verts = np.concatenate(verts)
+    normals = np.concatenate(normals)
+    light = np.array([0.5 * side, 0.5 * side, 0.9 * side])
+    return verts, normals, light
+
+
+def synthetic_F(n, n_rows=None, row0=0, seed=1, row_sum=0.9, device="cuda", ld=None):
+    """C5 solver-only matrix, generated on the device in row blocks: entries uniform(0,1), zero diagonal,
+    every row rescaled to sum `row_sum`.  Rows [row0, row0+n_rows) of the n x n matrix (fp32, ld >= n)."""
+    import torch
+    n_rows = n - row0 if n_rows is None else n_rows
+    ld = (n + 3) // 4 * 4 if ld is None else ld
+    F = torch.empty((n_rows, ld), dtype=torch.float32, device=device)
+    blk = 2048
+    for r in range(0, n_rows, blk):
+        m = min(blk, n_rows - r)
+        g = torch.Generator(device=device)
+        g.manual_seed(seed * 1000003 + row0 + r)   # depends on the GLOBAL row only: shards agree with the whole
+        x = torch.rand((m, n), generator=g, device=device, dtype=torch.float32)
+        idx = torch.arange(m, device=device)
+        x[idx, row0 + r + idx] = 0.0
+        x *= (row_sum / x.sum(dim=1, keepdim=True, dtype=torch.float64)).float()
+        F[r:r + m, :n] = x
+        if ld > n:
+            F[r:r + m, n:] = 0.0
+    return F

@@ -1,0 +1,140 @@
+"""GPU parity at BASELINE.json's full sizes: a sample against the oracle plus size-independent properties
+(closest-ness by re-tracing with tmax, any-hit == closest-hit != miss, tile shards == whole frame,
+known-answer fixed point for the 64 K-patch solve)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    import raytracer_amd
+    return raytracer_amd
+
+
+@pytest.fixture(scope="module")
+def soup(rt):
+    from raytracer_amd import workloads
+    tris = workloads.soup(1 << 20, seed=1)
+    scene = rt.Scene(tris)
+    cam = rt.Camera.from_cam14(workloads.SOUP_CAM14, workloads.SOUP_RES)
+    return tris, scene, cam
+
+
+def frame(rt, scene, cam, **kw):
+    import torch
+    out = torch.zeros(cam.x_res * cam.y_res * 24, dtype=torch.uint8, device="cuda")
+    scene.primary_dev(cam, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, **kw)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_c3_soup_frame_vs_oracle_sample_and_properties(rt, oracle, soup):
+    import torch
+    from raytracer_amd import workloads
+    tris, scene, cam = soup
+    info = scene.info()
+    assert info.n_tris == 1 << 20 and info.max_depth <= 30
+    d_hits = frame(rt, scene, cam, tile=(64, 64))
+    hits = d_hits.cpu().numpy().view(rt.HIT_DTYPE)
+    n = len(hits)
+    hit = hits["tri"] != rt.MISS
+    assert 0.5 < hit.mean() < 0.95
+    # (1) 300 000 random pixels against the oracle (its own BVH, the reference's Möller–Trumbore): bit-exact
+    rng = np.random.default_rng(11)
+    pix = np.stack([rng.integers(0, cam.y_res, 300000), rng.integers(0, cam.x_res, 300000)], 1).astype(np.uint32)
+    d = oracle.primary_dirs(oracle.raster_details(workloads.SOUP_CAM14, cam.x_res, cam.y_res), pix)
+    o = np.tile(workloads.SOUP_CAM14[:3], (len(d), 1))
+    h = oracle.bvh_build(tris)
+    (tri, t, u, v), _ = oracle.bvh_closest_hit(h, o, d)
+    oracle.bvh_free(h)
+    got = hits[pix[:, 0].astype(np.int64) * cam.x_res + pix[:, 1]]
+    assert np.array_equal(got["tri"], np.where(tri < 0, rt.MISS, tri).astype(np.uint32))
+    assert np.array_equal(got["t"], t)
+    assert np.array_equal(got["u"], u.astype(np.float32)) and np.array_equal(got["v"], v.astype(np.float32))
+    # and 2 000 of them against brute force over all 1 Mi triangles (no BVH on either side of the comparison)
+    tb, ttb, _, _ = oracle.closest_hit(tris, o[:2000], d[:2000])
+    assert np.array_equal(tb, tri[:2000]) and np.array_equal(ttb, t[:2000])
+    # (2) whole frame through the ray-buffer path: same records; any-hit == (closest != miss)
+    st = torch.cuda.current_stream().cuda_stream
+    rays = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+    rt.primary_rays_dev(cam, rays.data_ptr(), stream=st)
+    out2 = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+    scene.cast_dev(rays.data_ptr(), n, out2.data_ptr(), stream=st)
+    occ = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    scene.occluded_dev(rays.data_ptr(), n, occ.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, d_hits)
+    assert np.array_equal(occ.cpu().numpy().astype(bool), hit)
+    # (3) closest-ness: with tmax = t nothing is hit (no triangle has 0 < t' < t); with tmax just above t the
+    #     same record comes back
+    r = rays.cpu().numpy().view(rt.RAY_DTYPE).copy()
+    sel = np.nonzero(hit)[0][::3]
+    r1 = r[sel]; r1["tmax"] = hits["t"][sel]
+    assert (scene.Cast(r1)["tri"] == rt.MISS).all()
+    assert (scene.Occluded(r1) == 0).all()
+    r1["tmax"] = np.nextafter(hits["t"][sel], np.inf)
+    assert scene.Cast(r1).tobytes() == hits[sel].tobytes()
+    # (4) tile shards of two 'ranks' (different tile shape) put together == the frame
+    a = frame(rt, scene, cam, tile=(128, 32), tile_first=0, tile_stride=2)
+    b = frame(rt, scene, cam, tile=(128, 32), tile_first=1, tile_stride=2)
+    assert torch.equal(torch.maximum(a, b), d_hits) and int((torch.minimum(a, b) != 0).sum()) == 0
+    # (5) work counters are sane
+    counts = torch.zeros(2, dtype=torch.int64, device="cuda")
+    scene.primary_work_dev(cam, counts.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    visits, tests = (int(x) for x in counts.cpu())
+    assert n < visits < 400 * n and hit.sum() <= tests < 100 * n
+
+
+def test_c3_triangle_order_does_not_matter(rt, soup):
+    """Permuting the input triangles permutes the ids and changes nothing else (a different BVH is built)."""
+    from raytracer_amd import workloads
+    tris, scene, cam = soup
+    small = rt.Camera.from_cam14(workloads.SOUP_CAM14, (480, 270))
+    h0 = frame(rt, scene, small, tile=(0, 0)).cpu().numpy().view(rt.HIT_DTYPE)
+    perm = np.random.default_rng(2).permutation(len(tris))
+    s2 = rt.Scene(tris[perm])
+    h1 = frame(rt, s2, small, tile=(0, 0)).cpu().numpy().view(rt.HIT_DTYPE)
+    m = h0["tri"] != rt.MISS
+    assert np.array_equal(m, h1["tri"] != rt.MISS)
+    assert np.array_equal(perm[h1["tri"][m]], h0["tri"][m])
+    assert np.array_equal(h0["t"], h1["t"]) and np.array_equal(h0["u"], h1["u"]) and np.array_equal(h0["v"], h1["v"])
+
+
+def test_c5_solver_known_answer_64k(rt):
+    """64 K patches, 16 GiB F with every row summing to 0.9: E = (1 − 0.9ρ)·c has the fixed point B ≡ c."""
+    import torch
+    from raytracer_amd import workloads
+    n = 65536
+    F = workloads.synthetic_F(n, seed=1)
+    # rows of the matrix against numpy on a few rows
+    rows = [0, 1, 4099, n - 1]
+    Fr = F[rows].cpu().numpy().astype(np.float64)
+    assert np.allclose(Fr.sum(1), 0.9, atol=1e-5) and all(Fr[k, r] == 0 for k, r in enumerate(rows))
+    rho = np.array([0.7, 0.5, 0.3])
+    c = np.array([100.0, 20.0, 3.0])
+    E = torch.from_numpy(np.tile(((1 - 0.9 * rho) * c).astype(np.float32), (n, 1))).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    # one sweep from a random B against numpy on the sampled rows
+    B0 = torch.rand((n, 3), device="cuda") * 10
+    B1 = torch.zeros_like(B0)
+    norms = torch.zeros(3, dtype=torch.float64, device="cuda")
+    rt.jacobi_sweep_dev(F.data_ptr(), n, n, 0, n, rho, E.data_ptr(), B0.data_ptr(), B1.data_ptr(), norms.data_ptr(), st)
+    torch.cuda.synchronize()
+    want = E[rows].cpu().numpy().astype(np.float64) + rho[None, :] * (Fr @ B0.cpu().numpy().astype(np.float64))
+    assert np.max(np.abs(B1[rows].cpu().numpy() - want) / want) < 2e-7
+    # the whole solve
+    B = torch.zeros_like(E)
+    stats = rt.api.rtmi_solve_stats()
+    rc = rt.lib.rtmi_radiosity_solve_dev(F.data_ptr(), n, n, 0, n, rho.ctypes.data, E.data_ptr(), B.data_ptr(), 1e-6, 200, 2,
+                                         None, None, rt.api.C.byref(stats), st)
+    assert rc == 0, rt.lib.rtmi_last_error()
+    got = B.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(got - c[None, :]) / np.linalg.norm(np.tile(c, (n, 1))) < 1e-4     # the north star's bar
+    assert np.max(np.abs(got / c[None, :] - 1)) < 2e-5
+    assert 5 < stats.sweeps < 60

@@ -1,0 +1,310 @@
+"""GPU parity: the HIP path (through the C ABI of librtmi.so) against the oracle and the golden vectors
+produced by the compiled reference.  Bit-exact (==) for hit ids, t, u, v, visibility bits and form
+factors (fp32 storage of the oracle's double); the solve within 1e-4 relative L2 (north star)."""
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["test1", "test2", "test5", "test6", "test7", "scene_room_bed_sample"]
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    import raytracer_amd
+    return raytracer_amd
+
+
+def primary_frame(rt, scene, cam, tile=(64, 64), tile_first=0, tile_stride=1, fill=None):
+    import torch
+    n = cam.x_res * cam.y_res
+    out = torch.zeros(n * rt.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    if fill is not None:
+        out.fill_(fill)
+    scene.primary_dev(cam, out.data_ptr(), tile=tile, tile_first=tile_first, tile_stride=tile_stride,
+                      stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out.cpu().numpy().view(rt.HIT_DTYPE)
+
+
+def ids(tri):
+    """oracle ids (-1 = miss) -> rtmi ids"""
+    return np.where(tri < 0, 0xFFFFFFFF, tri).astype(np.uint32)
+
+
+def test_g1_triangle_intersection_bit_exact(rt):
+    g = load_golden("g1_mt.npz")
+    t, u, v = rt.triangle_intersection(g["o"], g["d"], g["v0"], g["v1"], g["v2"])
+    assert np.array_equal(t, g["t"]) and np.array_equal(u, g["u"]) and np.array_equal(v, g["v"])
+
+
+@pytest.mark.parametrize("stem", SCENES)
+def test_g2_primary_closest_hit_bit_exact(rt, oracle, stem):
+    g = load_golden("g2_%s.npz" % stem)
+    scene = rt.Scene(g["tris"], g["tri_obj"])
+    cam = rt.Camera.from_cam14(g["cam"], g["res"])
+    O, dR, dU = cam.raster_details()
+    assert np.array_equal(np.concatenate([O, dR, dU]), g["raster"][9:18])     # RasterDetails, rasterizer.cpp:40-56
+    hits = primary_frame(rt, scene, cam)
+    k = g["pix"][:, 0].astype(np.int64) * cam.x_res + g["pix"][:, 1]
+    got = hits[k]
+    # golden = the reference's own triangle_intersection, brute force over the original triangles
+    assert np.array_equal(got["tri"], ids(g["tri"]))
+    assert np.array_equal(got["t"], g["t"])
+    assert np.array_equal(got["u"], g["u"].astype(np.float32)) and np.array_equal(got["v"], g["v"].astype(np.float32))
+    hit = g["tri"] >= 0
+    assert np.array_equal(got["object"][hit], g["tri_obj"][g["tri"][hit]])
+    # Scene::Cast through the reference's BSP: same hit/miss, distance to rounding
+    if int(g["bsp_rc"]) == 0:
+        hm = g["cast_hit"].astype(bool)
+        assert np.array_equal(hm, got["tri"] != rt.MISS)
+        assert np.max(np.abs(g["cast_dist"][hm] - got["t"][hm]) / got["t"][hm]) < 1e-12
+    # the whole frame, by checksum of the reference's full-frame brute force
+    tri_full = np.where(hits["tri"] == rt.MISS, -1, hits["tri"].astype(np.int64)).astype("<i4")
+    assert int((tri_full >= 0).sum()) == int(g["full_hits"])
+    assert zlib.crc32(tri_full.tobytes()) == int(g["full_tri_crc32"])
+    assert zlib.crc32(hits["t"].astype("<f8").tobytes()) == int(g["full_t_crc32"])
+
+
+def test_g2_ray_buffer_path_equals_generated_primaries(rt):
+    """rtmi_primary_rays_dev + rtmi_closest_hit_dev == rtmi_primary_closest_hit_dev, and the host-pointer
+    entry equals the device-pointer entry."""
+    import torch
+    g = load_golden("g2_scene_room_bed_sample.npz")
+    scene = rt.Scene(g["tris"], g["tri_obj"])
+    cam = rt.Camera.from_cam14(g["cam"], g["res"])
+    n = cam.x_res * cam.y_res
+    ref = primary_frame(rt, scene, cam)
+    rays = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rt.primary_rays_dev(cam, rays.data_ptr(), stream=st)
+    scene.cast_dev(rays.data_ptr(), n, out.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(rt.HIT_DTYPE)
+    assert got.tobytes() == ref.tobytes()
+    hrays = rays.cpu().numpy().view(rt.RAY_DTYPE)
+    got2 = scene.Cast(hrays[::7])
+    assert got2.tobytes() == ref[::7].tobytes()
+    occ = scene.Occluded(hrays[::7])
+    assert np.array_equal(occ.astype(bool), ref[::7]["tri"] != rt.MISS)
+
+
+def test_g2_tiles_shard_without_overlap(rt):
+    """Image tiles dealt round-robin to 3 'ranks' (tile_first = rank, tile_stride = 3): every pixel is written by
+    exactly one rank, and the union equals the unsharded frame — the multi-GPU path for ray queries."""
+    g = load_golden("g2_test1.npz")
+    scene = rt.Scene(g["tris"], g["tri_obj"])
+    cam = rt.Camera.from_cam14(g["cam"], g["res"])
+    full = primary_frame(rt, scene, cam, tile=(0, 0))
+    parts = [primary_frame(rt, scene, cam, tile=(48, 40), tile_first=r, tile_stride=3, fill=0xAB) for r in range(3)]
+    raw = [p.view(np.uint8).reshape(-1, 24) for p in parts]
+    written = np.stack([(r != 0xAB).any(axis=1) for r in raw])
+    assert np.array_equal(written.sum(0), np.ones(len(full), np.int64))
+    union = np.where(written[0][:, None], raw[0], np.where(written[1][:, None], raw[1], raw[2]))
+    assert union.tobytes() == full.tobytes()
+
+
+def test_g3_shadow_and_ao_any_hit(rt):
+    g = load_golden("g2_test1.npz")
+    scene = rt.Scene(g["tris"], g["tri_obj"])
+    occ = scene.Occluded(rt.make_rays(g["shadow_o"], g["shadow_d"]))                  # shader.cpp:131
+    assert np.array_equal(occ, g["shadow_occluded"])
+    ao = scene.Occluded(rt.make_rays(g["ao_o"], g["ao_d"], tmax=2.0))                 # shader.cpp:226
+    assert np.array_equal(ao, g["ao_occluded"])
+    hit = scene.Occluded(rt.make_rays(g["ao_o"], g["ao_d"]))
+    assert np.array_equal(hit, g["ao_hit"])
+    ch = scene.Cast(rt.make_rays(g["ao_o"], g["ao_d"]))
+    assert np.array_equal(ch["t"][g["ao_hit"] == 1], g["ao_dist"][g["ao_hit"] == 1])
+
+
+@pytest.mark.parametrize("stem", ["radiosity_test", "practice_room_enclosed"])
+def test_g4_visibility_and_light_bits(rt, stem):
+    g = load_golden("g4_%s.npz" % stem)
+    scene = rt.Scene(g["verts"])
+    rad = rt.Radiosity(scene, g["normals"], g["light_center"])
+    vis = rad.isVisibleXiToXj(g["ej"], g["xi"], g["xj"])                              # radiosity.cpp:231-262
+    assert np.array_equal(vis, g["vis"])
+    # radiosity.cpp:279-290: ray xi + 1e-5·n_i -> Unit(C − xi), blocked ⇔ any hit
+    x = g["lx"]; n_i = g["normals"][g["li"]]
+    dv = g["light_center"][None, :] - x
+    l2 = dv[:, 0] * dv[:, 0] + dv[:, 1] * dv[:, 1] + dv[:, 2] * dv[:, 2]
+    d = dv / np.sqrt(l2)[:, None]
+    o = x + 1e-5 * n_i
+    assert np.array_equal(scene.Occluded(rt.make_rays(o, d)), g["light_blocked"])
+
+
+@pytest.mark.parametrize("stem", ["radiosity_test", "practice_room_enclosed"])
+def test_g4_form_factors_and_solve(rt, oracle, stem):
+    g = load_golden("g4_%s.npz" % stem)
+    ne = len(g["verts"])
+    scene = rt.Scene(g["verts"])
+    rad = rt.Radiosity(scene, g["normals"], g["light_center"])
+    FF = rad.findFormFactor(samples=int(g["S"]), light_samples=int(g["SL"]), seed=int(g["seed"]))
+    F = FF.cpu().numpy()[:, : ne + 1]
+    # the fixture's F is the formula of radiosity.cpp:305-333 / 264-303 in double on the seeded points; the
+    # device evaluates the same doubles and rounds once to fp32
+    assert np.array_equal(F, g["F"].astype(np.float32))
+    rad.progressiveRefinement(tol_rel=1e-7, check_every=1)
+    assert rad.stats.sweeps < 200 and rad.stats.rel_change <= 1e-7
+    B = rad.setRadiosityForAllElements()
+    # vs the reference's own progressiveRefinement output on that F, and the exact fixed point
+    Bref = g["B_ref"][:ne]
+    assert np.linalg.norm(B - Bref) / np.linalg.norm(Bref) < 1e-4
+    Bd = oracle.direct_solve(g["F"])[:ne]
+    assert np.linalg.norm(B - Bd) / np.linalg.norm(Bd) < 2e-6     # fp32 storage of F and B
+    assert float(rad.B[ne, 0]) == 68500.0
+    # sharded rows give the same rows
+    half = (ne + 1) // 2
+    top = rad.findFormFactor(samples=int(g["S"]), light_samples=int(g["SL"]), seed=int(g["seed"]), row0=0, n_rows=half)
+    assert np.array_equal(top.cpu().numpy()[:, : ne + 1], F[:half])
+    bot = rad.findFormFactor(samples=int(g["S"]), light_samples=int(g["SL"]), seed=int(g["seed"]), row0=half)
+    assert np.array_equal(bot.cpu().numpy()[:, : ne + 1], F[half:])
+
+
+def test_form_factors_light_mean_flag(rt, oracle):
+    g = load_golden("g4_practice_room_enclosed.npz")
+    ne = len(g["verts"])
+    scene = rt.Scene(g["verts"])
+    rad = rt.Radiosity(scene, g["normals"], g["light_center"])
+    F = rad.findFormFactor(samples=1, light_samples=int(g["SL"]), seed=7, flags=rt.FF_LIGHT_MEAN).cpu().numpy()
+    fl = oracle.light_terms(g["verts"], g["normals"], g["light_center"], int(g["SL"]), 7, mirror_bug=0)
+    assert np.array_equal(F[:ne, ne], fl.astype(np.float32))
+    assert np.all(F[ne] == 0)
+
+
+def test_closed_box_form_factors_rows(rt, oracle):
+    """C2-type geometry (closed box, 12·k² patches): a few rows of F against the oracle, bit-exact in fp32."""
+    from raytracer_amd import workloads
+    verts, normals, light = workloads.closed_box(6)              # 432 patches
+    n = len(verts)
+    scene = rt.Scene(verts)
+    rad = rt.Radiosity(scene, normals, light)
+    rows = [0, 5, 217, n - 1]
+    for r in rows:
+        got = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=r, n_rows=1).cpu().numpy()[0]
+        want = oracle.form_factors(verts, normals, 10, 1, row0=r, n_rows=1)[0]
+        fl = oracle.light_terms(verts, normals, light, 30, 1, mirror_bug=1, row0=r, n_rows=1)
+        assert np.array_equal(got[:n], want.astype(np.float32))
+        assert got[n] == np.float32(fl[0])
+        assert want.sum() > 0.3                                    # a closed box: most of the hemisphere is covered
+
+
+@pytest.mark.parametrize("n_tris,n_rays", [(1, 4096), (5, 4096), (3000, 60000)])
+def test_soup_closest_and_any_hit_vs_brute_force(rt, oracle, n_tris, n_rays):
+    from raytracer_amd import workloads
+    tris = workloads.soup(n_tris, seed=3, edge=0.2)
+    rng = np.random.default_rng(5)
+    o = rng.uniform(-1.5, 1.5, (n_rays, 3))
+    d = rng.normal(size=(n_rays, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    tmax = np.where(rng.random(n_rays) < 0.5, 1e20, rng.uniform(0.1, 3.0, n_rays))
+    scene = rt.Scene(tris)
+    got = scene.Cast(rt.make_rays(o, d, tmax))
+    tri, t, u, v = oracle.closest_hit(tris, o, d, tmax)
+    assert np.array_equal(got["tri"], ids(tri))
+    assert np.array_equal(got["t"], t)
+    assert np.array_equal(got["u"], u.astype(np.float32)) and np.array_equal(got["v"], v.astype(np.float32))
+    assert np.array_equal(scene.Occluded(rt.make_rays(o, d, tmax)), oracle.any_hit(tris, o, d, tmax))
+    if n_tris >= 1000:
+        assert (tri >= 0).sum() > 1000
+
+
+def test_ties_on_shared_edges_and_duplicates(rt, oracle):
+    """Rays aimed exactly at shared vertices / edges of a grid and at duplicated triangles: equal t ->
+    smallest original id, as the reference's in-order scan (object.cpp:143-168)."""
+    k = 8
+    g = np.arange(k + 1, dtype=np.float64)
+    tris = []
+    for i in range(k):
+        for j in range(k):
+            p00, p10, p11, p01 = (g[i], g[j], 0.0), (g[i + 1], g[j], 0.0), (g[i + 1], g[j + 1], 0.0), (g[i], g[j + 1], 0.0)
+            tris.append(p00 + p10 + p11)
+            tris.append(p00 + p11 + p01)
+    tris = np.array(tris + tris)                                    # every triangle twice
+    gx, gy = np.meshgrid(np.arange(0, k + 0.01, 0.5), np.arange(0, k + 0.01, 0.5), indexing="ij")
+    o = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, 3.0)], 1)
+    d = np.tile([0.0, 0.0, -1.0], (len(o), 1))
+    scene = rt.Scene(tris)
+    got = scene.Cast(rt.make_rays(o, d))
+    tri, t, u, v = oracle.closest_hit(tris, o, d)
+    assert (tri >= 0).all() and np.array_equal(got["tri"], ids(tri)) and np.array_equal(got["t"], t)
+    assert (tri < len(tris) // 2).all()
+
+
+def test_empty_and_degenerate_inputs(rt):
+    scene = rt.Scene(np.zeros((0, 9)))
+    rays = rt.make_rays([[0, 0, 0]], [[0, 0, 1]])
+    h = scene.Cast(rays)
+    assert h["tri"][0] == rt.MISS and h["t"][0] == 0.0
+    assert scene.Occluded(rays)[0] == 0
+    assert len(scene.Cast(rays[:0])) == 0
+    # zero-area triangles never hit (det window), and do not break the build
+    deg = np.zeros((7, 9)); deg[:, 0] = 1.0
+    s2 = rt.Scene(deg)
+    assert s2.Cast(rays)["tri"][0] == rt.MISS
+    with pytest.raises(rt.RtmiError):
+        bad = np.zeros((1, 9)); bad[0, 0] = np.nan
+        rt.Scene(bad)
+    with pytest.raises(rt.RtmiError):
+        rt.Radiosity(scene, np.zeros((0, 3)))
+
+
+@pytest.mark.parametrize("n", [11, 257, 1000])
+def test_jacobi_sweep_vs_oracle_rgb(rt, oracle, n):
+    import torch
+    rng = np.random.default_rng(n)
+    F = rng.random((n, n)).astype(np.float32)
+    np.fill_diagonal(F, 0)
+    F *= (0.9 / F.sum(1))[:, None].astype(np.float32)
+    rho = np.array([0.84, 0.37, 0.7])
+    E = (rng.random((n, 3)) * 100).astype(np.float32)
+    ld = (n + 3) // 4 * 4
+    Fp = np.zeros((n, ld), np.float32); Fp[:, :n] = F
+    dF = torch.from_numpy(Fp).cuda(); dE = torch.from_numpy(E).cuda()
+    Bold = torch.from_numpy((rng.random((n, 3)) * 50).astype(np.float32)).cuda()
+    Bnew = torch.zeros_like(Bold)
+    norms = torch.zeros(3, dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    # two half-sweeps (row shards) = one sweep
+    h = n // 2
+    rt.jacobi_sweep_dev(dF.data_ptr(), ld, n, 0, h, rho, dE.data_ptr(), Bold.data_ptr(), Bnew.data_ptr(), norms.data_ptr(), st)
+    rt.jacobi_sweep_dev(dF[h:].data_ptr(), ld, n, h, n - h, rho, dE.data_ptr(), Bold.data_ptr(), Bnew.data_ptr(),
+                        norms.data_ptr(), st)
+    torch.cuda.synchronize()
+    want = E.astype(np.float64) + rho[None, :] * (F.astype(np.float64) @ Bold.cpu().numpy().astype(np.float64))
+    got = Bnew.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - want) / np.abs(want)) < 2e-7          # one fp32 rounding of a double accumulation
+    nm = norms.cpu().numpy()
+    diff = got - Bold.cpu().numpy()
+    assert abs(nm[0] - (diff ** 2).sum()) / nm[0] < 1e-12 and abs(nm[1] - ((got - E) ** 2).sum()) / nm[1] < 1e-12
+    assert nm[2] == np.abs(diff).max()
+    # whole solve vs the oracle's double Jacobi
+    dB = torch.zeros_like(dE)
+    stats = rt.api.rtmi_solve_stats()
+    rc = rt.lib.rtmi_radiosity_solve_dev(dF.data_ptr(), ld, n, 0, n, rho.ctypes.data, dE.data_ptr(), dB.data_ptr(), 1e-7,
+                                         500, 1, None, None, rt.api.C.byref(stats), st)
+    assert rc == 0
+    Bo, sweeps = oracle.jacobi_rgb(F, rho, E, tol_rel=1e-12)
+    got = dB.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(got - Bo) / np.linalg.norm(Bo) < 1e-6
+    assert 5 < stats.sweeps < 500 and stats.rel_change <= 1e-7
+
+
+def test_jacobi_argument_errors(rt):
+    import torch
+    x = torch.zeros(64, device="cuda")
+    rho = np.array([0.7, 0.7, 0.7])
+    with pytest.raises(rt.RtmiError):
+        rt.jacobi_sweep_dev(x.data_ptr(), 3, 3, 0, 3, rho, x.data_ptr(), x.data_ptr(), x.data_ptr() + 16, x.data_ptr(), 0)  # ld % 4
+    with pytest.raises(rt.RtmiError):
+        rt.jacobi_sweep_dev(x.data_ptr(), 4, 3, 2, 3, rho, x.data_ptr(), x.data_ptr(), x.data_ptr() + 16, x.data_ptr(), 0)  # rows > n
+    with pytest.raises(rt.RtmiError):
+        rt.jacobi_sweep_dev(x.data_ptr(), 4, 3, 0, 3, rho, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 0)       # in place

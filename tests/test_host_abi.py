@@ -1,0 +1,126 @@
+"""CPU-side checks: the C-ABI library loads and exports exactly what include/rtmi.h declares, the host-only
+entry points behave, the product never touches oracle/, and the rank-sharding logic (world_size 2, gloo)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def header_symbols():
+    h = open(os.path.join(ROOT, "include", "rtmi.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtmi_[a-z_0-9]+)\s*\(", h)) - {"rtmi_exchange_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    import raytracer_amd as rt
+    syms = header_symbols()
+    assert sorted(rt.SYMBOLS) == syms
+    L = ctypes.CDLL(rt.LIB_PATH)
+    for s in syms:
+        assert hasattr(L, s), s
+    out = subprocess.check_output(["nm", "-D", "--defined-only", rt.LIB_PATH]).decode()
+    exported = sorted(set(re.findall(r" T (rtmi_[a-z_0-9]+)", out)))
+    assert exported == syms
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    import raytracer_amd as rt
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert rt.lib.rtmi_device_count() == 0
+    with pytest.raises(rt.RtmiError):
+        rt.Scene(np.zeros((1, 9)))
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "raytracer_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle_py" not in txt and "liboracle" not in txt and "rt_oracle" not in txt, f
+
+
+@pytest.mark.parametrize("stem", ["test1", "test2", "test5", "test6", "test7", "scene_room_bed_sample"])
+def test_camera_setup_matches_reference_raster_details(stem):
+    """rtmi_camera_setup runs on the host: RasterDetails (rasterizer.cpp:40-56) bit for bit."""
+    import raytracer_amd as rt
+    g = load_golden("g2_%s.npz" % stem)
+    cam = rt.Camera.from_cam14(g["cam"], g["res"])
+    O, dR, dU = cam.raster_details()
+    assert np.array_equal(np.concatenate([O, dR, dU]), g["raster"][9:18])
+    assert (cam.x_res, cam.y_res) == tuple(int(v) for v in g["res"])
+    with pytest.raises(rt.RtmiError):
+        rt.Camera(g["cam"][0:3], g["cam"][3:6], g["cam"][6:9], 1.0, [-1, 1], [-1, 1], 0, 10)
+
+
+def test_row_and_tile_sharding_cover_everything_once():
+    from raytracer_amd import multi
+    for n, w in [(65536, 8), (49, 2), (11, 4), (5, 8), (3889, 3)]:
+        seen = np.zeros(n, int)
+        for r in range(w):
+            r0, nr, blk = multi.rows_of_rank(n, r, w)
+            seen[r0:r0 + nr] += 1
+            assert nr <= blk and r0 == min(n, r * blk)
+        assert (seen == 1).all()
+    for (x, y, tw, th, w) in [(3840, 2160, 64, 64, 8), (500, 400, 48, 40, 3), (17, 9, 16, 16, 2)]:
+        tot = sum(multi.pixels_of_rank(x, y, tw, th, r, w) for r in range(w))
+        assert tot == x * y
+        tiles = sorted(t for r in range(w) for t in multi.tiles_of_rank(x, y, tw, th, r, w))
+        assert tiles == list(range(len(tiles)))
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import numpy as np, torch, torch.distributed as dist
+from raytracer_amd import multi
+rank, world = int(sys.argv[2]), int(sys.argv[3])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "g4_practice_room_enclosed.npz"))
+F = g["F"].astype(np.float32); n = F.shape[0]
+rho = np.array([0.7, 0.7, 0.7])
+E = np.zeros((n, 3), np.float32); E[n - 1] = 68500.0
+row0, n_rows, blk = multi.rows_of_rank(n, rank, world)
+Fl = F[row0:row0 + n_rows].astype(np.float64)          # this rank's rows only
+def sweep(B_old, B_new, norms):                       # CPU stand-in for the HIP sweep (tests only)
+    bo = B_old.numpy()[:n].astype(np.float64)
+    bn = (E[row0:row0 + n_rows].astype(np.float64) + rho[None, :] * (Fl @ bo)).astype(np.float32)
+    B_new[row0:row0 + n_rows] = torch.from_numpy(bn)
+    d = bn.astype(np.float64) - bo[row0:row0 + n_rows]
+    norms[0] += float((d ** 2).sum()); norms[1] += float(((bn - E[row0:row0 + n_rows]) ** 2).sum())
+    norms[2] = max(float(norms[2]), float(np.abs(d).max()) if len(d) else 0.0)
+r = multi.solve_sharded(sweep, torch.from_numpy(E), n, tol_rel=1e-7, max_sweeps=500, check_every=3)
+np.save(sys.argv[5] + ".%d.npy" % rank, r.B.numpy())
+print(rank, r.sweeps, r.rel_change)
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_solve_world2_gloo(tmp_path, oracle):
+    """Two ranks, gloo: F row-sharded, all-gather of B per sweep — every rank ends with the reference's B."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    out = str(tmp_path / "B")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, out], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    g = load_golden("g4_practice_room_enclosed.npz")
+    B0, B1 = np.load(out + ".0.npy"), np.load(out + ".1.npy")
+    assert np.array_equal(B0, B1)
+    ne = len(g["verts"])
+    Bd = oracle.direct_solve(g["F"])
+    assert np.linalg.norm(B0[:ne, 0] - Bd[:ne]) / np.linalg.norm(Bd[:ne]) < 1e-5
+    assert np.linalg.norm(B0[:ne, 0] - g["B_ref"][:ne]) / np.linalg.norm(g["B_ref"][:ne]) < 1e-4
+    assert B0[ne, 0] == 68500.0
