@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (tools/profile_gpu.sh) into profiles/<tag>_rocprof.md and
+profiles/traffic.json.  HBM traffic follows MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB;
+on gfx950 FETCH_SIZE reads half the bytes of a wide (16 B/lane) coalesced streaming read, so it is
+doubled for k_jacobi_sweep (exactly that pattern); for the traversal kernel (scattered 16-B loads) the
+factor is uncalibrated and both the raw and the doubled figure are listed."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+KERNELS = ["k_jacobi_sweep", "k_primary_closest", "k_form_factors", "k_primary_work", "k_trace_rays"]
+
+
+def short(name):
+    for k in KERNELS:
+        if k in name:
+            return k
+    return None
+
+
+lines = ["# rocprofv3 summary `%s` — `python3 bench.py --steps 5 --warmup 2 --no-cpu --ff-rows 32` on one MI355X" % tag, ""]
+lines += ["## --kernel-trace --stats (rtmi kernels; torch helper kernels that build the synthetic inputs omitted)", "",
+          "| kernel | calls | avg ms | min ms | max ms | % of GPU time |", "|---|---|---|---|---|---|"]
+for row in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))):
+    k = short(row["Name"])
+    if k:
+        lines.append("| %s | %s | %.4f | %.4f | %.4f | %s |" % (k, row["Calls"], float(row["AverageNs"]) / 1e6, float(row["MinNs"]) / 1e6,
+                                                         float(row["MaxNs"]) / 1e6, row["Percentage"]))
+# launch geometry from the trace
+geo = {}
+for row in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))):
+    k = short(row["Kernel_Name"])
+    if k and k not in geo:
+        geo[k] = row
+lines += ["", "| kernel | grid (threads) | workgroup | LDS B/wg | VGPR | SGPR | scratch |", "|---|---|---|---|---|---|---|"]
+for k, r in geo.items():
+    lines.append("| %s | %s | %s | %s | %s | %s | %s |" % (k, r.get("Grid_Size", r.get("Grid_Size_X")), r.get("Workgroup_Size", r.get("Workgroup_Size_X")),
+                                                      r.get("LDS_Block_Size"), r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("Scratch_Size")))
+
+pmc = defaultdict(lambda: defaultdict(list))     # kernel -> counter -> values per dispatch
+dur = defaultdict(list)
+for f in sorted(glob.glob(os.path.join(src, "pmc*", "pmc_counter_collection.csv"))):
+    for row in csv.DictReader(open(f)):
+        k = short(row["Kernel_Name"])
+        if k:
+            pmc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+lines += ["", "## --pmc passes (one run per counter group; averages per dispatch)", ""]
+traffic = {}
+for k in KERNELS:
+    if k not in pmc:
+        continue
+    lines += ["### %s" % k, "", "| counter | avg per dispatch |", "|---|---|"]
+    avg = {c: sum(v) / len(v) for c, v in pmc[k].items()}
+    for c in sorted(avg):
+        lines.append("| %s | %.6g |" % (c, avg[c]))
+    lines.append("")
+    if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+        rd, wr = avg["FETCH_SIZE"] * 1024, avg["WRITE_SIZE"] * 1024
+        lines.append("HBM-side bytes per dispatch: FETCH_SIZE %.4g B raw (x2 = %.4g B, gfx950 wide-read correction), WRITE_SIZE %.4g B." % (rd, 2 * rd, wr))
+        traffic[k] = {"fetch_raw": rd, "write": wr, "hbm_bytes": 2 * rd + wr}
+    if "TCC_HIT_sum" in avg:
+        lines.append("L2 hit rate = TCC_HIT/(TCC_HIT+TCC_MISS) = %.3f." % (avg["TCC_HIT_sum"] / (avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])))
+    if "SQ_WAVE_CYCLES" in avg and "SQ_ACTIVE_INST_VALU" in avg:
+        lines.append("Wave-cycle shares: WAIT_ANY %.2f, WAIT_INST_ANY %.2f, ACTIVE_INST_ANY %.2f; VALU-active share of wave cycles %.2f; VALU insts per wave %.0f." % (
+            avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"], avg["SQ_WAIT_INST_ANY"] / avg["SQ_WAVE_CYCLES"], avg["SQ_ACTIVE_INST_ANY"] / avg["SQ_WAVE_CYCLES"],
+            avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_WAVE_CYCLES"], avg["SQ_INSTS_VALU"] / avg["SQ_WAVES"]))
+    if "SQ_THREAD_CYCLES_VALU" in avg and "SQ_ACTIVE_INST_VALU" in pmc[k]:
+        pass
+    lines.append("")
+os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+open(os.path.join(root, "profiles", tag + "_rocprof.md"), "w").write("\n".join(lines) + "\n")
+# traffic.json: what bench.py reports as roofline.traffic (keyed by the launch it was measured on)
+n = 65536
+out = {}
+if "k_jacobi_sweep" in traffic:
+    out["k_jacobi_sweep"] = {"bytes_per_launch": 4.0 * n * n, "hbm_bytes": traffic["k_jacobi_sweep"]["hbm_bytes"], "source": tag}
+if "k_primary_closest" in traffic:
+    out["k_primary_closest"] = {"rays_per_launch": 3840 * 2160, "hbm_bytes": traffic["k_primary_closest"]["hbm_bytes"],
+                                "hbm_bytes_uncorrected": traffic["k_primary_closest"]["fetch_raw"] + traffic["k_primary_closest"]["write"], "source": tag}
+json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
+print("\n".join(lines))
