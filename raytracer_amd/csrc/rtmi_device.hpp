@@ -134,8 +134,10 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 	const RayF r = make_rayf(ox, oy, oz, dx, dy, dz, S.absmax);
 	int sp = 0;
 	int cur = S.root_ref;
-	while (cur != kSentinel) {
-		if (cur >= 0) {
+	// "while-while": all lanes first walk inner nodes until each holds a leaf (or is finished), then the
+	// wave tests leaf triangles together — the two bodies never serialise inside one iteration.
+	while (true) {
+		while (cur >= 0) {
 			const GNode *np = S.nodes + cur;
 			if (COUNT) ++w->nodes;
 			const float4 a = np->a, b = np->b, c = np->c;
@@ -158,36 +160,36 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 			} else {
 				cur = kSentinel;
 			}
-		} else {
-			const uint32_t code = ~(uint32_t)cur;
-			const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
-			bool done = false;
-			for (uint32_t k = first; k < first + cnt; ++k) {
-				const GTri &T = S.tris[k];
-				if (COUNT) ++w->tests;
-				double u = 0.0, v = 0.0;
-				const double t = mt_exact(ox, oy, oz, dx, dy, dz, T, u, v);
-				if (ANY) {
-					if (t > 0.0 && t < tmax) {
-						h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = k;
-						done = true;
-						break;
-					}
-				} else {
-					if (t > 0.0 && (best > t || (t == best && h.orig != RTMI_MISS && T.orig < h.orig))) {
-						best = t;
-						tbest = f32_above(best);
-						h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = k;
-					}
+		}
+		if (cur == kSentinel) break;
+		const uint32_t code = ~(uint32_t)cur;
+		const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+		bool done = false;
+		for (uint32_t k = first; k < first + cnt; ++k) {
+			const GTri &T = S.tris[k];
+			if (COUNT) ++w->tests;
+			double u = 0.0, v = 0.0;
+			const double t = mt_exact(ox, oy, oz, dx, dy, dz, T, u, v);
+			if (ANY) {
+				if (t > 0.0 && t < tmax) {
+					h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = k;
+					done = true;
+					break;
+				}
+			} else {
+				if (t > 0.0 && (best > t || (t == best && h.orig != RTMI_MISS && T.orig < h.orig))) {
+					best = t;
+					tbest = f32_above(best);
+					h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = k;
 				}
 			}
-			if (done) break;
-			if (sp > 0) {
-				--sp;
-				cur = stack[sp * kBlock];
-			} else {
-				cur = kSentinel;
-			}
+		}
+		if (done) break;
+		if (sp > 0) {
+			--sp;
+			cur = stack[sp * kBlock];
+		} else {
+			cur = kSentinel;
 		}
 	}
 }

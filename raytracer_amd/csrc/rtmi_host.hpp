@@ -9,6 +9,7 @@ struct rtmi_scene {
 	rtmi::SceneDev dev;
 	uint64_t n_tris;
 	int device;
+	uint32_t stack_bytes; // dynamic LDS of every traversal kernel: (BVH depth + 1) ints per lane
 	rtmi_scene_info info;
 };
 

@@ -69,7 +69,7 @@ __device__ __forceinline__ bool visible(const SceneDev &S, const PatchesDev &P, 
 __global__ __launch_bounds__(kBlock) void k_visible_points(SceneDev S, PatchesDev P, uint64_t m,
                                                            const int32_t *__restrict__ ej, const double *__restrict__ xi,
                                                            const double *__restrict__ xj, uint8_t *__restrict__ vis) {
-	__shared__ int stack[kStackDepth * kBlock];
+	extern __shared__ int stack[]; // rtmi_scene::stack_bytes: (BVH depth + 1) entries per lane
 	const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	if (k >= m) return;
 	const D3 a = d3(xi[3 * k], xi[3 * k + 1], xi[3 * k + 2]), b = d3(xj[3 * k], xj[3 * k + 1], xj[3 * k + 2]);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void k_form_factors(SceneDev S, PatchesDev 
                                                          double cz, uint32_t samples, uint32_t light_samples,
                                                          uint64_t seed, uint32_t flags, uint32_t row0, uint32_t n_rows,
                                                          uint32_t n, float *__restrict__ F, uint64_t ld) {
-	__shared__ int stack_all[kStackDepth * kBlock];
+	extern __shared__ int stack_all[]; // rtmi_scene::stack_bytes
 	int *stack = stack_all + threadIdx.x;
 	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	if (idx >= (uint64_t)n_rows * n) return;
@@ -304,7 +304,7 @@ int rtmi_visible_points(rtmi_patches *P, uint64_t m, const int32_t *ej, const do
 	     hipMemcpy(d_xj, xj, 24 * m, hipMemcpyHostToDevice) == hipSuccess;
 	int rc = ok ? 0 : fail(std::string(who) + ": device allocation or upload failed");
 	if (!rc) {
-		hipLaunchKernelGGL(k_visible_points, dim3((uint32_t)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
+		hipLaunchKernelGGL(k_visible_points, dim3((uint32_t)((m + kBlock - 1) / kBlock)), dim3(kBlock), P->scene->stack_bytes, nullptr,
 		                   P->scene->dev, pdev(P), m, d_ej, d_xi, d_xj, d_vis);
 		rc = launch_check(who);
 	}
@@ -331,7 +331,7 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 	if (grid > 0x7fffffffull) return fail(std::string(who) + ": too many entries for one launch; shard the rows");
 	const double cx = light_center ? light_center[0] : 0.0, cy = light_center ? light_center[1] : 0.0,
 	             cz = light_center ? light_center[2] : 0.0;
-	hipLaunchKernelGGL(k_form_factors, dim3((uint32_t)grid), dim3(kBlock), 0, (hipStream_t)stream, P->scene->dev, pdev(P),
+	hipLaunchKernelGGL(k_form_factors, dim3((uint32_t)grid), dim3(kBlock), P->scene->stack_bytes, (hipStream_t)stream, P->scene->dev, pdev(P),
 	                   light_center != nullptr, cx, cy, cz, samples, light_samples, seed, flags, row0, n_rows, n, d_F, ld);
 	return launch_check(who);
 }

@@ -23,7 +23,7 @@ int fail(const std::string &msg) {
 template <bool ANY>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(SceneDev S, const rtmi_ray *__restrict__ rays, uint64_t n,
                                                        rtmi_hit *__restrict__ out, uint8_t *__restrict__ occluded) {
-	__shared__ int stack[kStackDepth * kBlock];
+	extern __shared__ int stack[]; // rtmi_scene::stack_bytes: (BVH depth + 1) entries per lane
 	const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	if (k >= n) return;
 	const rtmi_ray R = rays[k];
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_closest(SceneDev S, rtmi_cam
                                                             uint32_t tile_first, uint32_t tile_stride,
                                                             uint32_t blocks_x, uint32_t blocks_per_tile,
                                                             rtmi_hit *__restrict__ out) {
-	__shared__ int stack[kStackDepth * kBlock];
+	extern __shared__ int stack[]; // rtmi_scene::stack_bytes: (BVH depth + 1) entries per lane
 	const uint32_t local_tile = blockIdx.x / blocks_per_tile, b = blockIdx.x % blocks_per_tile;
 	const uint32_t tile = tile_first + local_tile * tile_stride;
 	const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_closest(SceneDev S, rtmi_cam
 // (one visit = two child boxes), counts[1] += exact triangle tests.  Diagnostic, not on the hot path.
 __global__ __launch_bounds__(kBlock) void k_primary_work(SceneDev S, rtmi_camera cam, double sx, double sy,
                                                          unsigned long long *__restrict__ counts) {
-	__shared__ int stack[kStackDepth * kBlock];
+	extern __shared__ int stack[]; // rtmi_scene::stack_bytes: (BVH depth + 1) entries per lane
 	const uint32_t bx = (cam.x_res + 15) / 16;
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const uint32_t j = (blockIdx.x % bx) * 16 + (wave & 1) * 8 + (lane & 7);
@@ -158,6 +158,8 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	std::memcpy(s->info.scene_hi, bvh.hi, sizeof bvh.hi);
 	if (hipGetDevice(&s->device) != hipSuccess) { delete s; fail("hipGetDevice failed"); return nullptr; }
 	s->dev.nodes = nullptr; s->dev.tris = nullptr; s->dev.root_ref = kSentinel; s->dev.absmax = 0.f;
+	// one push per inner node on a root-to-leaf path at most: depth entries, +1 spare
+	s->stack_bytes = (bvh.depth + 1u) * kBlock * (uint32_t)sizeof(int);
 	if (n == 0) return s;
 
 	// leaf-ordered triangles
@@ -257,7 +259,7 @@ static int trace_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, rtmi_hit
 	if (!d_rays || (ANY ? !d_occ : !d_out)) return fail(std::string(who) + ": NULL buffer");
 	if (n > (uint64_t)0x7fffffff * kBlock) return fail(std::string(who) + ": too many rays for one launch");
 	const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
-	hipLaunchKernelGGL(k_trace_rays<ANY>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s->dev, d_rays, n, d_out, d_occ);
+	hipLaunchKernelGGL(k_trace_rays<ANY>, dim3(grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, d_rays, n, d_out, d_occ);
 	return launch_check(who);
 }
 
@@ -408,7 +410,7 @@ int rtmi_primary_closest_hit_dev(rtmi_scene *s, const rtmi_camera *cam, double s
 	const uint32_t bx = (tile_w + 15) / 16, by = (tile_h + 15) / 16;
 	const uint64_t grid = local * bx * by;
 	if (grid > 0x7fffffffull) return fail(std::string(who) + ": grid too large");
-	hipLaunchKernelGGL(k_primary_closest, dim3((uint32_t)grid), dim3(kBlock), 0, (hipStream_t)stream, s->dev, *cam, sx, sy,
+	hipLaunchKernelGGL(k_primary_closest, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, *cam, sx, sy,
 	                   tile_w, tile_h, tiles_x, tile_first, tile_stride, bx, bx * by, d_out);
 	return launch_check(who);
 }
@@ -420,7 +422,7 @@ int rtmi_primary_work_dev(rtmi_scene *s, const rtmi_camera *cam, double sx, doub
 	if (cam->x_res == 0 || cam->y_res == 0) return fail(std::string(who) + ": zero resolution");
 	const uint64_t grid = (uint64_t)((cam->x_res + 15) / 16) * ((cam->y_res + 15) / 16);
 	if (grid > 0x7fffffffull) return fail(std::string(who) + ": grid too large");
-	hipLaunchKernelGGL(k_primary_work, dim3((uint32_t)grid), dim3(kBlock), 0, (hipStream_t)stream, s->dev, *cam, sx, sy,
+	hipLaunchKernelGGL(k_primary_work, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, *cam, sx, sy,
 	                   (unsigned long long *)d_counts);
 	return launch_check(who);
 }
