@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtmi.so")
+LIB_PATH = os.environ.get("RTMI_LIB", os.path.join(_HERE, "librtmi.so"))   # RTMI_LIB: kernel-variant experiments
 
 MISS = 0xFFFFFFFF
 INFINITY = 1.0e20

@@ -30,8 +30,15 @@ struct __attribute__((aligned(16))) GTri {
 
 constexpr int kStackDepth = 32;   // LDS traversal stack entries per lane (builder caps the depth)
 constexpr int kBlock = 256;       // threads per workgroup in every traversal kernel
-constexpr int kSentinel = INT32_MIN;
-constexpr uint32_t kMaxFirst = 1u << 27;
+constexpr int kSentinel = INT32_MIN;      // lane state: no node left (ray finished, or lane idle)
+constexpr uint32_t kGuard = 1u << 26;      // wave-iterations after which trace_queue gives up (safety net)
+constexpr int kLeaf = INT32_MIN + 1;      // lane state: working through the triangles of a leaf
+// Traversal kernels are latency-bound: ask the register allocator for at least this many waves per SIMD.
+#ifndef RTMI_WAVES
+#define RTMI_WAVES 6
+#endif
+#define RTMI_TRAVERSAL_KERNEL __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTMI_WAVES, 8)))
+constexpr uint32_t kMaxFirst = 1u << 27; // leaf refs ~((first << 3) | cnt-1) stay above kLeaf
 
 struct SceneDev {
 	const GNode *nodes;
@@ -122,7 +129,11 @@ __device__ __forceinline__ float f32_above(double x) { return __double2float_ru(
 //              original id (the in-order scan of Render2/object.cpp:143-168 keeps the first).
 // ANY = true : stop at the first triangle with 0 < t < tmax (Render2/shader.cpp:131,226).
 // COUNT = true additionally tallies node visits and triangle tests (the roofline's work count).
-struct Work { uint32_t nodes, tests; };
+struct Work { uint32_t nodes, tests, node_slots, test_slots; }; // *_slots: 64 per wave-iteration (lane occupancy = nodes / node_slots)
+__device__ __forceinline__ uint32_t wave_slots() { // 64 on the first active lane of the wave, 0 elsewhere
+	const unsigned long long m = __ballot(1);
+	return (uint32_t)(__ffsll((long long)m) - 1) == (threadIdx.x & 63u) ? 64u : 0u;
+}
 
 template <bool ANY, bool COUNT = false>
 __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, double oz, double dx, double dy,
@@ -139,7 +150,7 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 	while (true) {
 		while (cur >= 0) {
 			const GNode *np = S.nodes + cur;
-			if (COUNT) ++w->nodes;
+			if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
 			const float4 a = np->a, b = np->b, c = np->c;
 			const int4 d = np->d;
 			float t0, t1;
@@ -167,7 +178,7 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 		bool done = false;
 		for (uint32_t k = first; k < first + cnt; ++k) {
 			const GTri &T = S.tris[k];
-			if (COUNT) ++w->tests;
+			if (COUNT) { ++w->tests; w->test_slots += wave_slots(); }
 			double u = 0.0, v = 0.0;
 			const double t = mt_exact(ox, oy, oz, dx, dy, dz, T, u, v);
 			if (ANY) {
@@ -190,6 +201,141 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 			cur = stack[sp * kBlock];
 		} else {
 			cur = kSentinel;
+		}
+	}
+}
+
+// ---------------------------------------------------------------- persistent waves over a work queue
+// A workgroup owns `n_items` work items (rays) and an LDS counter.  Every lane traces one ray at a time;
+// whenever at least `thresh` lanes of a wave are idle, the wave claims that many items with ONE LDS atomic
+// (ballot + mbcnt give each idle lane its slot) and the idle lanes start new rays while the others carry
+// on.  Ray lengths in a scene are close to exponentially distributed, so without this a wave runs for
+// the longest of its 64 rays (measured 20 % lane occupancy in the node loop on the 1 Mi-triangle soup).
+//   fetch(item, R) -> bool   fill the ray of a work item (false: no ray for this item)
+//   emit(item, R, h)         consume the hit record
+struct RayD { double ox, oy, oz, dx, dy, dz, tmax; };
+// What a lane keeps of its best hit while traversing: the triangle's position in the leaf-ordered array
+// (original id and object are read back from there when the ray retires), t (in `best`), and u, v already
+// rounded to the float the hit record stores.  Few registers = more waves per SIMD.
+struct HitQ { double t; float u, v; uint32_t pos; }; // pos == RTMI_MISS: no hit (then t = 0)
+
+// UNIFORM_O: every ray of the launch starts at (uox, uoy, uoz) (primary rays: the eye) — the origin then
+// lives in scalar registers instead of six VGPRs per lane; fetch() need not fill R.ox..oz.
+template <bool ANY, bool COUNT, bool UNIFORM_O, class Fetch, class Emit>
+__device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *counter, uint32_t n_items, int thresh,
+                                            int vote_node, int vote_leaf, double uox, double uoy, double uoz, Fetch fetch,
+                                            Emit emit, Work *w = nullptr) {
+	const uint32_t lane = threadIdx.x & 63u;
+	RayD R = {0, 0, 0, 0, 0, 1, 0};
+	RayF r = {0, 0, 0, 0, 0, 0, 1, 1, 1};
+	HitQ h = {0.0, 0.f, 0.f, RTMI_MISS};
+	double best = 0.0;
+	float tbest = 0.f;
+	int sp = 0, cur = kSentinel;
+	uint32_t item = 0, tk = 0, tend = 0; // [tk, tend): triangles of the leaf this lane is working through (cur == kLeaf)
+	bool have = false; // this lane holds a ray (in flight, or finished and not yet emitted)
+	bool more = true;  // the queue still has items (wave-uniform)
+	uint32_t guard = 0;
+	while (true) {
+		if (have && cur == kSentinel) {
+			h.t = h.pos != RTMI_MISS ? best : 0.0;
+			emit(item, h);
+			have = false;
+		}
+		if (more) {
+			const unsigned long long idle = __ballot(!have);
+			const int nidle = __popcll(idle);
+			if (nidle >= thresh) {
+				uint32_t base = 0;
+				const uint32_t leader = (uint32_t)(__ffsll((long long)idle) - 1);
+				if (lane == leader) base = (uint32_t)atomicAdd(counter, nidle);
+				base = __shfl(base, (int)leader, 64);
+				if (!have) {
+					const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+					const uint32_t idx = base + below;
+					if (idx < n_items && fetch(idx, R)) {
+						item = idx;
+						have = true;
+						h.u = h.v = 0.f; h.pos = RTMI_MISS;
+						best = R.tmax;
+						tbest = f32_above(best);
+						r = make_rayf(UNIFORM_O ? uox : R.ox, UNIFORM_O ? uoy : R.oy, UNIFORM_O ? uoz : R.oz, R.dx, R.dy, R.dz, S.absmax);
+						sp = 0;
+						cur = S.root_ref;
+					}
+				}
+				if (base + (uint32_t)nidle >= n_items) more = false;
+			}
+		}
+		if (cur < 0 && cur != kSentinel && cur != kLeaf) { // a leaf reference came up (child, pop or a single-leaf root): unpack it
+			const uint32_t code = ~(uint32_t)cur;
+			tk = code >> 3;
+			tend = tk + (code & 7u) + 1u;
+			cur = kLeaf;
+		}
+		if (++guard > kGuard) break; // a wave that cannot finish must still end: never reached on valid input
+		// Vote: the wave runs ONE node step or ONE triangle step per iteration, whichever has more lanes
+		// waiting (a triangle step costs about twice a node step).  Lanes of the other kind simply wait, so
+		// no lane ever runs ahead speculatively and the visited set is exactly the sequential one.
+		const int n_node = __popcll(__ballot(cur >= 0)), n_leaf = __popcll(__ballot(cur == kLeaf));
+		if (n_node + n_leaf == 0) {
+			if (!more && __ballot(have) == 0ull) break;
+			continue;
+		}
+		if (n_node * vote_node >= n_leaf * vote_leaf) {
+			if (cur >= 0) {
+				const GNode *np = S.nodes + cur;
+				if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
+				const float4 a = np->a, b = np->b, c = np->c;
+				const int4 d = np->d;
+				float t0, t1;
+				const bool h0 = slab(a.x, a.y, a.z, a.w, c.x, c.y, r, tbest, t0);
+				const bool h1 = slab(b.x, b.y, b.z, b.w, c.z, c.w, r, tbest, t1);
+				if (h0 && h1) {
+					const bool swap = t1 < t0;
+					cur = swap ? d.y : d.x;
+					stack[sp * kBlock] = swap ? d.x : d.y;
+					++sp;
+				} else if (h0) {
+					cur = d.x;
+				} else if (h1) {
+					cur = d.y;
+				} else if (sp > 0) {
+					--sp;
+					cur = stack[sp * kBlock];
+				} else {
+					cur = kSentinel;
+				}
+			}
+		} else {
+			if (cur == kLeaf) {
+				if (COUNT) { ++w->tests; w->test_slots += wave_slots(); }
+				const GTri T = S.tris[tk]; // the whole 80-B record in one round trip
+				double u = 0.0, v = 0.0;
+				const double t = mt_exact(UNIFORM_O ? uox : R.ox, UNIFORM_O ? uoy : R.oy, UNIFORM_O ? uoz : R.oz, R.dx, R.dy, R.dz, T, u, v);
+				bool done = false;
+				if (ANY) {
+					if (t > 0.0 && t < best) { // best == tmax throughout
+						best = t;
+						h.u = (float)u; h.v = (float)v; h.pos = tk;
+						done = true;
+					}
+				} else {
+					// strict minimum; equal t -> smaller original id (the rare tie reads the holder's id back)
+					if (t > 0.0 && (best > t || (t == best && h.pos != RTMI_MISS && T.orig < S.tris[h.pos].orig))) {
+						best = t;
+						tbest = f32_above(best);
+						h.u = (float)u; h.v = (float)v; h.pos = tk;
+					}
+				}
+				++tk;
+				if (done || (tk == tend && sp == 0)) {
+					cur = kSentinel;
+				} else if (tk == tend) {
+					--sp;
+					cur = stack[sp * kBlock];
+				}
+			}
 		}
 	}
 }

@@ -19,25 +19,53 @@ int fail(const std::string &msg) {
 }
 
 // ------------------------------------------------------------------------------------------- kernels
-// Rays from a buffer: lane k of the grid takes ray k (callers that care about coherence sort first).
-template <bool ANY>
-__global__ __launch_bounds__(kBlock) void k_trace_rays(SceneDev S, const rtmi_ray *__restrict__ rays, uint64_t n,
-                                                       rtmi_hit *__restrict__ out, uint8_t *__restrict__ occluded) {
-	extern __shared__ int stack[]; // rtmi_scene::stack_bytes: (BVH depth + 1) entries per lane
-	const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-	if (k >= n) return;
-	const rtmi_ray R = rays[k];
-	double tmax = R.tmax;
-	if (!(tmax > 0.0) || tmax > RTMI_INFINITY) tmax = RTMI_INFINITY;
-	Hit h;
-	trace<ANY>(S, R.o[0], R.o[1], R.o[2], R.d[0], R.d[1], R.d[2], tmax, stack + threadIdx.x, h);
-	if (ANY) {
-		occluded[k] = h.orig != RTMI_MISS ? 1 : 0;
-	} else {
-		rtmi_hit o;
-		o.t = h.t; o.u = (float)h.u; o.v = (float)h.v; o.tri = h.orig; o.object = h.object;
-		out[k] = o;
+// Dynamic LDS of every traversal kernel: the lanes' stacks (rtmi_scene::stack_bytes) followed by the
+// workgroup's queue counter.
+__device__ __forceinline__ int *queue_counter(int *stack, uint32_t stack_bytes) {
+	int *c = stack + stack_bytes / sizeof(int);
+	if (threadIdx.x == 0) *c = 0;
+	__syncthreads();
+	return c;
+}
+
+// refill threshold and phase-vote weights of trace_queue (RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF override)
+struct Tune { int thresh, vote_node, vote_leaf; };
+
+// HitQ -> the record of include/rtmi.h (original id and object come from the triangle the lane remembered)
+__device__ __forceinline__ rtmi_hit hit_record(const SceneDev &S, const HitQ &h) {
+	rtmi_hit o;
+	o.t = h.t; o.u = h.u; o.v = h.v; o.tri = RTMI_MISS; o.object = RTMI_MISS;
+	if (h.pos != RTMI_MISS) {
+		const uint2 ids = *reinterpret_cast<const uint2 *>(&S.tris[h.pos].orig);
+		o.tri = ids.x; o.object = ids.y;
 	}
+	return o;
+}
+
+// Rays from a buffer: workgroup b owns rays [b·chunk, (b+1)·chunk) and works through them as a queue
+// (trace_queue); callers that care about coherence sort the buffer first.
+template <bool ANY>
+RTMI_TRAVERSAL_KERNEL void k_trace_rays(SceneDev S, uint32_t stack_bytes, const rtmi_ray *__restrict__ rays,
+                                                       uint64_t n, uint32_t chunk, Tune tune, rtmi_hit *__restrict__ out,
+                                                       uint8_t *__restrict__ occluded) {
+	extern __shared__ int stack[];
+	int *counter = queue_counter(stack, stack_bytes);
+	const uint64_t base = (uint64_t)blockIdx.x * chunk;
+	const uint32_t items = (uint32_t)(n - base < (uint64_t)chunk ? n - base : (uint64_t)chunk);
+	auto fetch = [&](uint32_t idx, RayD &R) {
+		const rtmi_ray q = rays[base + idx];
+		R.ox = q.o[0]; R.oy = q.o[1]; R.oz = q.o[2];
+		R.dx = q.d[0]; R.dy = q.d[1]; R.dz = q.d[2];
+		double tmax = q.tmax;
+		if (!(tmax > 0.0) || tmax > RTMI_INFINITY) tmax = RTMI_INFINITY;
+		R.tmax = tmax;
+		return true;
+	};
+	auto emit = [&](uint32_t idx, const HitQ &h) {
+		if (ANY) occluded[base + idx] = h.pos != RTMI_MISS ? 1 : 0;
+		else out[base + idx] = hit_record(S, h);
+	};
+	trace_queue<ANY, false, false>(S, stack + threadIdx.x, counter, items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
 }
 
 // Render2/rasterizer.cpp:230 — dir(i,j) = Unit(O + (j+sx)·dR − (i+sy)·dU), origin = eye.
@@ -46,54 +74,82 @@ __device__ __forceinline__ D3 primary_dir(const rtmi_camera &c, uint32_t i, uint
 	return unit((O + (j + sx) * dR) - (i + sy) * dU);
 }
 
-// Primary rays generated in registers, 0 input bytes per ray.  A workgroup owns a 16×16 pixel
-// block of one image tile, each of its 4 waves an 8×8 pixel square: 64 nearly parallel rays walk
-// the same nodes, so a wave's node fetches collapse to a few cache lines.
-__global__ __launch_bounds__(kBlock) void k_primary_closest(SceneDev S, rtmi_camera cam, double sx, double sy,
-                                                            uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x,
-                                                            uint32_t tile_first, uint32_t tile_stride,
-                                                            uint32_t blocks_x, uint32_t blocks_per_tile,
+struct PrimaryGrid {
+	uint32_t tile_w, tile_h, tiles_x, tile_first, tile_stride;
+	uint32_t blk_w, blk_h;            // pixels one workgroup owns (multiples of 8)
+	uint32_t blocks_x, blocks_per_tile;
+};
+
+// item k of a workgroup's blk_w × blk_h pixel block: consecutive runs of 64 items are 8×8 pixel squares, so
+// the rays a wave claims together are neighbours and walk the same nodes.
+__device__ __forceinline__ bool primary_pixel(const PrimaryGrid &g, const rtmi_camera &cam, uint32_t block, uint32_t k,
+                                              uint32_t &i, uint32_t &j) {
+	const uint32_t local_tile = block / g.blocks_per_tile, b = block % g.blocks_per_tile;
+	const uint32_t tile = g.tile_first + local_tile * g.tile_stride;
+	const uint32_t tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+	const uint32_t sq = k >> 6, in = k & 63u, sq_x = g.blk_w >> 3;
+	const uint32_t lx = (b % g.blocks_x) * g.blk_w + (sq % sq_x) * 8 + (in & 7u);
+	const uint32_t ly = (b / g.blocks_x) * g.blk_h + (sq / sq_x) * 8 + (in >> 3);
+	j = tx * g.tile_w + lx;
+	i = ty * g.tile_h + ly;
+	return lx < g.tile_w && ly < g.tile_h && j < cam.x_res && i < cam.y_res;
+}
+
+// Primary rays generated in registers, 0 input bytes per ray.
+RTMI_TRAVERSAL_KERNEL void k_primary_closest(SceneDev S, uint32_t stack_bytes, rtmi_camera cam, double sx,
+                                                            double sy, PrimaryGrid g, Tune tune,
                                                             rtmi_hit *__restrict__ out) {
-	extern __shared__ int stack[]; // rtmi_scene::stack_bytes: (BVH depth + 1) entries per lane
-	const uint32_t local_tile = blockIdx.x / blocks_per_tile, b = blockIdx.x % blocks_per_tile;
-	const uint32_t tile = tile_first + local_tile * tile_stride;
-	const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const uint32_t lx = (b % blocks_x) * 16 + (wave & 1) * 8 + (lane & 7);
-	const uint32_t ly = (b / blocks_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
-	const uint32_t j = tx * tile_w + lx, i = ty * tile_h + ly;
-	if (lx >= tile_w || ly >= tile_h || j >= cam.x_res || i >= cam.y_res) return;
-	const D3 d = primary_dir(cam, i, j, sx, sy);
-	Hit h;
-	trace<false>(S, cam.eye[0], cam.eye[1], cam.eye[2], d.x, d.y, d.z, RTMI_INFINITY, stack + threadIdx.x, h);
-	rtmi_hit o;
-	o.t = h.t; o.u = (float)h.u; o.v = (float)h.v; o.tri = h.orig; o.object = h.object;
-	out[(uint64_t)i * cam.x_res + j] = o;
+	extern __shared__ int stack[];
+	int *counter = queue_counter(stack, stack_bytes);
+	auto fetch = [&](uint32_t idx, RayD &R) {
+		uint32_t i, j;
+		if (!primary_pixel(g, cam, blockIdx.x, idx, i, j)) return false;
+		const D3 d = primary_dir(cam, i, j, sx, sy);
+		R.dx = d.x; R.dy = d.y; R.dz = d.z;
+		R.tmax = RTMI_INFINITY;
+		return true;
+	};
+	auto emit = [&](uint32_t idx, const HitQ &h) {
+		uint32_t i, j;
+		primary_pixel(g, cam, blockIdx.x, idx, i, j);
+		out[(uint64_t)i * cam.x_res + j] = hit_record(S, h);
+	};
+	trace_queue<false, false, true>(S, stack + threadIdx.x, counter, g.blk_w * g.blk_h, tune.thresh, tune.vote_node, tune.vote_leaf, cam.eye[0], cam.eye[1], cam.eye[2],
+	                                fetch, emit);
 }
 
 // Same rays as k_primary_closest (all tiles); only counts the traversal work: counts[0] += node visits
-// (one visit = two child boxes), counts[1] += exact triangle tests.  Diagnostic, not on the hot path.
-__global__ __launch_bounds__(kBlock) void k_primary_work(SceneDev S, rtmi_camera cam, double sx, double sy,
-                                                         unsigned long long *__restrict__ counts) {
-	extern __shared__ int stack[]; // rtmi_scene::stack_bytes: (BVH depth + 1) entries per lane
-	const uint32_t bx = (cam.x_res + 15) / 16;
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const uint32_t j = (blockIdx.x % bx) * 16 + (wave & 1) * 8 + (lane & 7);
-	const uint32_t i = (blockIdx.x / bx) * 16 + (wave >> 1) * 8 + (lane >> 3);
-	Work w = {0u, 0u};
-	if (j < cam.x_res && i < cam.y_res) {
+// (one visit = two child boxes), counts[1] += exact triangle tests, counts[2..3] += the lane slots the wave spent on
+// them (64 per wave-iteration: visits / slots = lane occupancy of that loop).  Diagnostic, not on the hot path.
+RTMI_TRAVERSAL_KERNEL void k_primary_work(SceneDev S, uint32_t stack_bytes, rtmi_camera cam, double sx, double sy,
+                                                         PrimaryGrid g, Tune tune, unsigned long long *__restrict__ counts) {
+	extern __shared__ int stack[];
+	int *counter = queue_counter(stack, stack_bytes);
+	const uint32_t lane = threadIdx.x & 63u;
+	Work w = {0u, 0u, 0u, 0u};
+	auto fetch = [&](uint32_t idx, RayD &R) {
+		uint32_t i, j;
+		if (!primary_pixel(g, cam, blockIdx.x, idx, i, j)) return false;
 		const D3 d = primary_dir(cam, i, j, sx, sy);
-		Hit h;
-		trace<false, true>(S, cam.eye[0], cam.eye[1], cam.eye[2], d.x, d.y, d.z, RTMI_INFINITY, stack + threadIdx.x, h, &w);
-	}
-	unsigned long long a = w.nodes, b = w.tests;
+		R.dx = d.x; R.dy = d.y; R.dz = d.z;
+		R.tmax = RTMI_INFINITY;
+		return true;
+	};
+	auto emit = [&](uint32_t, const HitQ &) {};
+	trace_queue<false, true, true>(S, stack + threadIdx.x, counter, g.blk_w * g.blk_h, tune.thresh, tune.vote_node, tune.vote_leaf, cam.eye[0], cam.eye[1], cam.eye[2],
+	                               fetch, emit, &w);
+	unsigned long long a = w.nodes, b = w.tests, c = w.node_slots, e = w.test_slots;
 	for (int off = 32; off > 0; off >>= 1) {
 		a += __shfl_xor(a, off, 64);
 		b += __shfl_xor(b, off, 64);
+		c += __shfl_xor(c, off, 64);
+		e += __shfl_xor(e, off, 64);
 	}
 	if (lane == 0) {
 		atomicAdd(&counts[0], a);
 		atomicAdd(&counts[1], b);
+		atomicAdd(&counts[2], c);
+		atomicAdd(&counts[3], e);
 	}
 }
 
@@ -137,13 +193,21 @@ static unsigned env_uint(const char *name, unsigned dflt) {
 	return v > 0 ? (unsigned)v : dflt;
 }
 
+static Tune refill_threshold() {
+	Tune t;
+	t.thresh = (int)std::min(64u, env_uint("RTMI_REFILL", 16));
+	t.vote_node = (int)env_uint("RTMI_VOTE_NODE", 1);
+	t.vote_leaf = (int)env_uint("RTMI_VOTE_LEAF", 1);
+	return t;
+}
+
 static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t n) {
 	if (n > 0 && !xyz) { fail("rtmi_scene_create: tri_xyz is NULL"); return nullptr; }
 	if (n >= kMaxFirst) { fail("rtmi_scene_create: more than 2^27-1 triangles"); return nullptr; }
 	for (uint64_t i = 0; i < 9 * n; ++i)
 		if (!std::isfinite(xyz[i])) { fail("rtmi_scene_create: non-finite vertex coordinate"); return nullptr; }
 	auto t0 = std::chrono::steady_clock::now();
-	const unsigned leaf = std::min(8u, env_uint("RTMI_LEAF", 4));
+	const unsigned leaf = std::min(8u, env_uint("RTMI_LEAF", 1));
 	const unsigned threads = std::min(env_uint("RTMI_BUILD_THREADS", std::max(1u, std::thread::hardware_concurrency())), 16u);
 	Bvh2 bvh = build_bvh2(xyz, n, leaf, kStackDepth - 2, threads);
 	if (n > 0 && bvh.depth > (uint32_t)kStackDepth - 1) { fail("rtmi_scene_create: BVH deeper than the traversal stack"); return nullptr; }
@@ -257,9 +321,12 @@ static int trace_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, rtmi_hit
 	if (check_scene(s, who)) return -1;
 	if (n == 0) return 0;
 	if (!d_rays || (ANY ? !d_occ : !d_out)) return fail(std::string(who) + ": NULL buffer");
-	if (n > (uint64_t)0x7fffffff * kBlock) return fail(std::string(who) + ": too many rays for one launch");
-	const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
-	hipLaunchKernelGGL(k_trace_rays<ANY>, dim3(grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, d_rays, n, d_out, d_occ);
+	const uint32_t chunk = env_uint("RTMI_CHUNK", 2048);
+	const Tune thresh = refill_threshold();
+	const uint64_t grid = (n + chunk - 1) / chunk;
+	if (grid > 0x7fffffffull) return fail(std::string(who) + ": too many rays for one launch");
+	hipLaunchKernelGGL(k_trace_rays<ANY>, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes + 16, (hipStream_t)stream, s->dev,
+	                   s->stack_bytes, d_rays, n, chunk, thresh, d_out, d_occ);
 	return launch_check(who);
 }
 
@@ -394,12 +461,9 @@ int rtmi_camera_setup(const double eye[3], const double lookat[3], const double 
 	return 0;
 }
 
-int rtmi_primary_closest_hit_dev(rtmi_scene *s, const rtmi_camera *cam, double sx, double sy, uint32_t tile_w,
-                                 uint32_t tile_h, uint32_t tile_first, uint32_t tile_stride, rtmi_hit *d_out,
-                                 void *stream) {
-	const char *who = "rtmi_primary_closest_hit_dev";
-	if (check_scene(s, who)) return -1;
-	if (!cam || !d_out) return fail(std::string(who) + ": NULL argument");
+// tiles -> workgroup blocks; returns the grid size (0: nothing to do), -1 on error
+static int64_t primary_grid(const rtmi_camera *cam, uint32_t tile_w, uint32_t tile_h, uint32_t tile_first, uint32_t tile_stride,
+                            PrimaryGrid &g, const char *who) {
 	if (cam->x_res == 0 || cam->y_res == 0) return fail(std::string(who) + ": zero resolution");
 	if (tile_w == 0 || tile_h == 0) { tile_w = cam->x_res; tile_h = cam->y_res; }
 	if (tile_stride == 0) return fail(std::string(who) + ": tile_stride must be >= 1");
@@ -407,11 +471,27 @@ int rtmi_primary_closest_hit_dev(rtmi_scene *s, const rtmi_camera *cam, double s
 	const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
 	if (tile_first >= n_tiles) return 0;
 	const uint64_t local = (n_tiles - tile_first + tile_stride - 1) / tile_stride;
-	const uint32_t bx = (tile_w + 15) / 16, by = (tile_h + 15) / 16;
-	const uint64_t grid = local * bx * by;
+	g.tile_w = tile_w; g.tile_h = tile_h; g.tiles_x = tiles_x; g.tile_first = tile_first; g.tile_stride = tile_stride;
+	g.blk_w = std::min(64u, (tile_w + 7) / 8 * 8);
+	g.blk_h = std::min(std::max(8u, env_uint("RTMI_BLK_H", 32) / 8 * 8), (tile_h + 7) / 8 * 8);
+	g.blocks_x = (tile_w + g.blk_w - 1) / g.blk_w;
+	g.blocks_per_tile = g.blocks_x * ((tile_h + g.blk_h - 1) / g.blk_h);
+	const uint64_t grid = local * g.blocks_per_tile;
 	if (grid > 0x7fffffffull) return fail(std::string(who) + ": grid too large");
-	hipLaunchKernelGGL(k_primary_closest, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, *cam, sx, sy,
-	                   tile_w, tile_h, tiles_x, tile_first, tile_stride, bx, bx * by, d_out);
+	return (int64_t)grid;
+}
+
+int rtmi_primary_closest_hit_dev(rtmi_scene *s, const rtmi_camera *cam, double sx, double sy, uint32_t tile_w,
+                                 uint32_t tile_h, uint32_t tile_first, uint32_t tile_stride, rtmi_hit *d_out,
+                                 void *stream) {
+	const char *who = "rtmi_primary_closest_hit_dev";
+	if (check_scene(s, who)) return -1;
+	if (!cam || !d_out) return fail(std::string(who) + ": NULL argument");
+	PrimaryGrid g;
+	const int64_t grid = primary_grid(cam, tile_w, tile_h, tile_first, tile_stride, g, who);
+	if (grid <= 0) return (int)grid;
+	hipLaunchKernelGGL(k_primary_closest, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes + 16, (hipStream_t)stream, s->dev,
+	                   s->stack_bytes, *cam, sx, sy, g, refill_threshold(), d_out);
 	return launch_check(who);
 }
 
@@ -419,11 +499,11 @@ int rtmi_primary_work_dev(rtmi_scene *s, const rtmi_camera *cam, double sx, doub
 	const char *who = "rtmi_primary_work_dev";
 	if (check_scene(s, who)) return -1;
 	if (!cam || !d_counts) return fail(std::string(who) + ": NULL argument");
-	if (cam->x_res == 0 || cam->y_res == 0) return fail(std::string(who) + ": zero resolution");
-	const uint64_t grid = (uint64_t)((cam->x_res + 15) / 16) * ((cam->y_res + 15) / 16);
-	if (grid > 0x7fffffffull) return fail(std::string(who) + ": grid too large");
-	hipLaunchKernelGGL(k_primary_work, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, *cam, sx, sy,
-	                   (unsigned long long *)d_counts);
+	PrimaryGrid g;
+	const int64_t grid = primary_grid(cam, 64, 64, 0, 1, g, who);
+	if (grid <= 0) return (int)grid;
+	hipLaunchKernelGGL(k_primary_work, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes + 16, (hipStream_t)stream, s->dev,
+	                   s->stack_bytes, *cam, sx, sy, g, refill_threshold(), (unsigned long long *)d_counts);
 	return launch_check(who);
 }
 
