@@ -37,7 +37,8 @@ constexpr int kLeaf = INT32_MIN + 1;      // lane state: working through the tri
 #ifndef RTMI_WAVES
 #define RTMI_WAVES 6
 #endif
-#define RTMI_TRAVERSAL_KERNEL __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTMI_WAVES, 8)))
+#define RTMI_TRAVERSAL_KERNEL_W(w) __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(w, 8)))
+#define RTMI_TRAVERSAL_KERNEL RTMI_TRAVERSAL_KERNEL_W(RTMI_WAVES)
 constexpr uint32_t kMaxFirst = 1u << 27; // leaf refs ~((first << 3) | cnt-1) stay above kLeaf
 
 struct SceneDev {
@@ -145,74 +146,94 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 	const RayF r = make_rayf(ox, oy, oz, dx, dy, dz, S.absmax);
 	int sp = 0;
 	int cur = S.root_ref;
-	// "while-while": all lanes first walk inner nodes until each holds a leaf (or is finished), then the
-	// wave tests leaf triangles together — the two bodies never serialise inside one iteration.
-	while (true) {
-		while (cur >= 0) {
-			const GNode *np = S.nodes + cur;
-			if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
-			const float4 a = np->a, b = np->b, c = np->c;
-			const int4 d = np->d;
-			float t0, t1;
-			const bool h0 = slab(a.x, a.y, a.z, a.w, c.x, c.y, r, tbest, t0);
-			const bool h1 = slab(b.x, b.y, b.z, b.w, c.z, c.w, r, tbest, t1);
-			if (h0 && h1) {
-				const bool swap = t1 < t0;
-				cur = swap ? d.y : d.x;
-				stack[sp * kBlock] = swap ? d.x : d.y;
-				++sp;
-			} else if (h0) {
-				cur = d.x;
-			} else if (h1) {
-				cur = d.y;
-			} else if (sp > 0) {
-				--sp;
-				cur = stack[sp * kBlock];
-			} else {
-				cur = kSentinel;
-			}
+	uint32_t tk = 0, tend = 0;
+	// All lanes start together and the wave runs until its last ray is done; per iteration it takes ONE node
+	// step or ONE triangle step, whichever more lanes wait for (see trace_queue for the refilling variant).
+	for (uint32_t guard = 0; guard < kGuard; ++guard) {
+		if (cur < 0 && cur != kSentinel && cur != kLeaf) {
+			const uint32_t code = ~(uint32_t)cur;
+			tk = code >> 3;
+			tend = tk + (code & 7u) + 1u;
+			cur = kLeaf;
 		}
-		if (cur == kSentinel) break;
-		const uint32_t code = ~(uint32_t)cur;
-		const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
-		bool done = false;
-		for (uint32_t k = first; k < first + cnt; ++k) {
-			const GTri &T = S.tris[k];
+		const int n_node = __popcll(__ballot(cur >= 0)), n_leaf = __popcll(__ballot(cur == kLeaf));
+		if (n_node + n_leaf == 0) break;
+		if (n_node >= n_leaf) {
+			if (cur >= 0) {
+				const GNode *np = S.nodes + cur;
+				if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
+				const float4 a = np->a, b = np->b, c = np->c;
+				const int4 d = np->d;
+				float t0, t1;
+				const bool h0 = slab(a.x, a.y, a.z, a.w, c.x, c.y, r, tbest, t0);
+				const bool h1 = slab(b.x, b.y, b.z, b.w, c.z, c.w, r, tbest, t1);
+				if (h0 && h1) {
+					const bool swap = t1 < t0;
+					cur = swap ? d.y : d.x;
+					stack[sp * kBlock] = swap ? d.x : d.y;
+					++sp;
+				} else if (h0) {
+					cur = d.x;
+				} else if (h1) {
+					cur = d.y;
+				} else if (sp > 0) {
+					--sp;
+					cur = stack[sp * kBlock];
+				} else {
+					cur = kSentinel;
+				}
+			}
+		} else if (cur == kLeaf) {
 			if (COUNT) { ++w->tests; w->test_slots += wave_slots(); }
+			const GTri T = S.tris[tk];
 			double u = 0.0, v = 0.0;
 			const double t = mt_exact(ox, oy, oz, dx, dy, dz, T, u, v);
+			bool done = false;
 			if (ANY) {
 				if (t > 0.0 && t < tmax) {
-					h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = k;
+					h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = tk;
 					done = true;
-					break;
 				}
 			} else {
 				if (t > 0.0 && (best > t || (t == best && h.orig != RTMI_MISS && T.orig < h.orig))) {
 					best = t;
 					tbest = f32_above(best);
-					h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = k;
+					h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = tk;
 				}
 			}
-		}
-		if (done) break;
-		if (sp > 0) {
-			--sp;
-			cur = stack[sp * kBlock];
-		} else {
-			cur = kSentinel;
+			++tk;
+			if (done || (tk == tend && sp == 0)) {
+				cur = kSentinel;
+			} else if (tk == tend) {
+				--sp;
+				cur = stack[sp * kBlock];
+			}
 		}
 	}
 }
 
 // ---------------------------------------------------------------- persistent waves over a work queue
+// refill threshold and phase-vote weights of trace_queue (RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF override)
+struct Tune { int thresh, vote_node, vote_leaf; };
+
+// Dynamic LDS of every traversal kernel: the lanes' stacks (rtmi_scene::stack_bytes) followed by the
+// workgroup's queue counter.
+__device__ __forceinline__ int *queue_counter(int *stack, uint32_t stack_bytes) {
+	int *c = stack + stack_bytes / sizeof(int);
+	if (threadIdx.x == 0) *c = 0;
+	__syncthreads();
+	return c;
+}
+
+
 // A workgroup owns `n_items` work items (rays) and an LDS counter.  Every lane traces one ray at a time;
 // whenever at least `thresh` lanes of a wave are idle, the wave claims that many items with ONE LDS atomic
 // (ballot + mbcnt give each idle lane its slot) and the idle lanes start new rays while the others carry
 // on.  Ray lengths in a scene are close to exponentially distributed, so without this a wave runs for
 // the longest of its 64 rays (measured 20 % lane occupancy in the node loop on the 1 Mi-triangle soup).
-//   fetch(item, R) -> bool   fill the ray of a work item (false: no ray for this item)
-//   emit(item, R, h)         consume the hit record
+//   fetch(item, R) -> bool    fill the first ray of a work item (false: no ray for this item)
+//   emit(item, h, R) -> bool  consume the hit record; true = R now holds the item's NEXT ray (form factors:
+//                             S samples per matrix entry, summed in sample order by the lane that owns it)
 struct RayD { double ox, oy, oz, dx, dy, dz, tmax; };
 // What a lane keeps of its best hit while traversing: the triangle's position in the leaf-ordered array
 // (original id and object are read back from there when the ray retires), t (in `best`), and u, v already
@@ -236,35 +257,46 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 	bool have = false; // this lane holds a ray (in flight, or finished and not yet emitted)
 	bool more = true;  // the queue still has items (wave-uniform)
 	uint32_t guard = 0;
+	auto start = [&]() { // R holds a new ray: reset the lane's traversal state
+		h.u = h.v = 0.f; h.pos = RTMI_MISS;
+		best = R.tmax;
+		tbest = f32_above(best);
+		r = make_rayf(UNIFORM_O ? uox : R.ox, UNIFORM_O ? uoy : R.oy, UNIFORM_O ? uoz : R.oz, R.dx, R.dy, R.dz, S.absmax);
+		sp = 0;
+		cur = S.root_ref;
+	};
 	while (true) {
-		if (have && cur == kSentinel) {
-			h.t = h.pos != RTMI_MISS ? best : 0.0;
-			emit(item, h);
-			have = false;
-		}
-		if (more) {
-			const unsigned long long idle = __ballot(!have);
-			const int nidle = __popcll(idle);
-			if (nidle >= thresh) {
-				uint32_t base = 0;
-				const uint32_t leader = (uint32_t)(__ffsll((long long)idle) - 1);
-				if (lane == leader) base = (uint32_t)atomicAdd(counter, nidle);
-				base = __shfl(base, (int)leader, 64);
-				if (!have) {
-					const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-					const uint32_t idx = base + below;
-					if (idx < n_items && fetch(idx, R)) {
-						item = idx;
-						have = true;
-						h.u = h.v = 0.f; h.pos = RTMI_MISS;
-						best = R.tmax;
-						tbest = f32_above(best);
-						r = make_rayf(UNIFORM_O ? uox : R.ox, UNIFORM_O ? uoy : R.oy, UNIFORM_O ? uoz : R.oz, R.dx, R.dy, R.dz, S.absmax);
-						sp = 0;
-						cur = S.root_ref;
+		// Retire + refill together, and only when enough lanes wait for it (or nothing else is left to do):
+		// emit/fetch can be long (form factors: sample points, cosines, a division), so they must not run
+		// for one lane at a time.
+		const bool fin = have && cur == kSentinel;
+		const int n_fin = __popcll(__ballot(fin)), n_free = more ? __popcll(__ballot(!have)) : 0;
+		const int n_busy = __popcll(__ballot(have && cur != kSentinel));
+		if (n_fin + n_free >= thresh || (n_busy == 0 && n_fin + n_free > 0)) {
+			if (fin) {
+				h.t = h.pos != RTMI_MISS ? best : 0.0;
+				if (emit(item, h, R)) start(); // the item wants another ray (R refilled): same lane carries on
+				else have = false;
+			}
+			if (more) {
+				const unsigned long long idle = __ballot(!have);
+				const int nidle = __popcll(idle);
+				if (nidle > 0) {
+					uint32_t base = 0;
+					const uint32_t leader = (uint32_t)(__ffsll((long long)idle) - 1);
+					if (lane == leader) base = (uint32_t)atomicAdd(counter, nidle);
+					base = __shfl(base, (int)leader, 64);
+					if (!have) {
+						const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+						const uint32_t idx = base + below;
+						if (idx < n_items && fetch(idx, R)) {
+							item = idx;
+							have = true;
+							start();
+						}
 					}
+					if (base + (uint32_t)nidle >= n_items) more = false;
 				}
-				if (base + (uint32_t)nidle >= n_items) more = false;
 			}
 		}
 		if (cur < 0 && cur != kSentinel && cur != kLeaf) { // a leaf reference came up (child, pop or a single-leaf root): unpack it
@@ -278,7 +310,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 		// waiting (a triangle step costs about twice a node step).  Lanes of the other kind simply wait, so
 		// no lane ever runs ahead speculatively and the visited set is exactly the sequential one.
 		const int n_node = __popcll(__ballot(cur >= 0)), n_leaf = __popcll(__ballot(cur == kLeaf));
-		if (n_node + n_leaf == 0) {
+		if (n_node + n_leaf == 0) { // nobody can step: finished lanes retire at the top of the next round
 			if (!more && __ballot(have) == 0ull) break;
 			continue;
 		}

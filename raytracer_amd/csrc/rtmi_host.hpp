@@ -16,5 +16,7 @@ struct rtmi_scene {
 namespace rtmi {
 extern thread_local std::string g_err;
 int fail(const std::string &msg);        // records msg for rtmi_last_error(), returns -1
-int launch_check(const char *who);       // hipGetLastError() after a launch -> 0 / -1
+int launch_check(const char *who);
+unsigned env_uint(const char *name, unsigned dflt); // tuning overrides from the environment
+Tune refill_threshold();                          // RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF       // hipGetLastError() after a launch -> 0 / -1
 } // namespace rtmi

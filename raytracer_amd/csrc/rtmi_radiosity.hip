@@ -66,7 +66,7 @@ __device__ __forceinline__ bool visible(const SceneDev &S, const PatchesDev &P, 
 	return sqrt(len2(p - yi)) < kEpsilon && dot(dir, d3(nj[0], nj[1], nj[2])) < 0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_visible_points(SceneDev S, PatchesDev P, uint64_t m,
+RTMI_TRAVERSAL_KERNEL void k_visible_points(SceneDev S, PatchesDev P, uint64_t m,
                                                            const int32_t *__restrict__ ej, const double *__restrict__ xi,
                                                            const double *__restrict__ xj, uint8_t *__restrict__ vis) {
 	extern __shared__ int stack[]; // rtmi_scene::stack_bytes: (BVH depth + 1) entries per lane
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void k_visible_points(SceneDev S, PatchesDe
 //   j <  n_patches, i != j : Render2/radiosity.cpp:305-333 (findFormFactorTerm)
 //   j == n_patches (light) : Render2/radiosity.cpp:264-303 (findFormFactorTermWithLight)
 //   i == n_patches or i == j : 0   (:382, :391-393)
-__global__ __launch_bounds__(kBlock) void k_form_factors(SceneDev S, PatchesDev P, bool has_light, double cx, double cy,
+RTMI_TRAVERSAL_KERNEL void k_form_factors(SceneDev S, PatchesDev P, bool has_light, double cx, double cy,
                                                          double cz, uint32_t samples, uint32_t light_samples,
                                                          uint64_t seed, uint32_t flags, uint32_t row0, uint32_t n_rows,
                                                          uint32_t n, float *__restrict__ F, uint64_t ld) {

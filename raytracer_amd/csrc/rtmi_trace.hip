@@ -19,18 +19,6 @@ int fail(const std::string &msg) {
 }
 
 // ------------------------------------------------------------------------------------------- kernels
-// Dynamic LDS of every traversal kernel: the lanes' stacks (rtmi_scene::stack_bytes) followed by the
-// workgroup's queue counter.
-__device__ __forceinline__ int *queue_counter(int *stack, uint32_t stack_bytes) {
-	int *c = stack + stack_bytes / sizeof(int);
-	if (threadIdx.x == 0) *c = 0;
-	__syncthreads();
-	return c;
-}
-
-// refill threshold and phase-vote weights of trace_queue (RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF override)
-struct Tune { int thresh, vote_node, vote_leaf; };
-
 // HitQ -> the record of include/rtmi.h (original id and object come from the triangle the lane remembered)
 __device__ __forceinline__ rtmi_hit hit_record(const SceneDev &S, const HitQ &h) {
 	rtmi_hit o;
@@ -61,9 +49,10 @@ RTMI_TRAVERSAL_KERNEL void k_trace_rays(SceneDev S, uint32_t stack_bytes, const 
 		R.tmax = tmax;
 		return true;
 	};
-	auto emit = [&](uint32_t idx, const HitQ &h) {
+	auto emit = [&](uint32_t idx, const HitQ &h, RayD &) {
 		if (ANY) occluded[base + idx] = h.pos != RTMI_MISS ? 1 : 0;
 		else out[base + idx] = hit_record(S, h);
+		return false;
 	};
 	trace_queue<ANY, false, false>(S, stack + threadIdx.x, counter, items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
 }
@@ -109,10 +98,11 @@ RTMI_TRAVERSAL_KERNEL void k_primary_closest(SceneDev S, uint32_t stack_bytes, r
 		R.tmax = RTMI_INFINITY;
 		return true;
 	};
-	auto emit = [&](uint32_t idx, const HitQ &h) {
+	auto emit = [&](uint32_t idx, const HitQ &h, RayD &) {
 		uint32_t i, j;
 		primary_pixel(g, cam, blockIdx.x, idx, i, j);
 		out[(uint64_t)i * cam.x_res + j] = hit_record(S, h);
+		return false;
 	};
 	trace_queue<false, false, true>(S, stack + threadIdx.x, counter, g.blk_w * g.blk_h, tune.thresh, tune.vote_node, tune.vote_leaf, cam.eye[0], cam.eye[1], cam.eye[2],
 	                                fetch, emit);
@@ -135,7 +125,7 @@ RTMI_TRAVERSAL_KERNEL void k_primary_work(SceneDev S, uint32_t stack_bytes, rtmi
 		R.tmax = RTMI_INFINITY;
 		return true;
 	};
-	auto emit = [&](uint32_t, const HitQ &) {};
+	auto emit = [&](uint32_t, const HitQ &, RayD &) { return false; };
 	trace_queue<false, true, true>(S, stack + threadIdx.x, counter, g.blk_w * g.blk_h, tune.thresh, tune.vote_node, tune.vote_leaf, cam.eye[0], cam.eye[1], cam.eye[2],
 	                               fetch, emit, &w);
 	unsigned long long a = w.nodes, b = w.tests, c = w.node_slots, e = w.test_slots;
@@ -186,14 +176,14 @@ __global__ void k_triangle_intersection(uint64_t n, const double *__restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------- scene
-static unsigned env_uint(const char *name, unsigned dflt) {
+unsigned env_uint(const char *name, unsigned dflt) {
 	const char *s = std::getenv(name);
 	if (!s || !*s) return dflt;
 	long v = std::strtol(s, nullptr, 10);
 	return v > 0 ? (unsigned)v : dflt;
 }
 
-static Tune refill_threshold() {
+Tune refill_threshold() {
 	Tune t;
 	t.thresh = (int)std::min(64u, env_uint("RTMI_REFILL", 16));
 	t.vote_node = (int)env_uint("RTMI_VOTE_NODE", 1);
