@@ -21,9 +21,12 @@ def soup(n_tris=1 << 20, seed=1, edge=0.01):
     return np.concatenate([c, c + e1, c + e2], axis=1)
 
 
-def closed_box(k, side=10.0):
-    """Cornell-type closed box: returns (verts n x 9, normals n x 3 pointing inward, light centre).
-    n = 12 k^2.  Wall order: z=0, z=side, y=0, y=side, x=0, x=side; rows of quads, 2 triangles per quad."""
+def closed_box(k, side=10.0, hole=0.0):
+    """Cornell-type box: returns (verts n x 9, normals n x 3 pointing inward, light centre).
+    n = 12 k^2 when closed.  Wall order: z=0, z=side, y=0, y=side, x=0, x=side; rows of quads, 2 triangles per quad.
+    hole > 0 removes the ceiling triangles whose centroid lies in the central square of width hole·side and
+    puts the light above the opening (the reference's light test asks for NO hit at any distance,
+    radiosity.cpp:290, so a light inside a closed box lights nothing)."""
     h = side / k
     g = np.arange(k) * h
     a, b = np.meshgrid(g, g, indexing="ij")
@@ -51,6 +54,11 @@ def closed_box(k, side=10.0):
     verts = np.concatenate(verts)
     normals = np.concatenate(normals)
     light = np.array([0.5 * side, 0.5 * side, 0.9 * side])
+    if hole > 0.0:
+        c = (verts[:, 0:3] + verts[:, 3:6] + verts[:, 6:9]) / 3.0
+        cut = (c[:, 2] == side) & (np.abs(c[:, 0] - 0.5 * side) < 0.5 * hole * side) & (np.abs(c[:, 1] - 0.5 * side) < 0.5 * hole * side)
+        verts, normals = verts[~cut], normals[~cut]
+        light = np.array([0.5 * side, 0.5 * side, 1.5 * side])
     return verts, normals, light
 
 
@@ -74,3 +82,44 @@ def synthetic_F(n, n_rows=None, row0=0, seed=1, row_sum=0.9, device="cuda", ld=N
         if ld > n:
             F[r:r + m, n:] = 0.0
     return F
+
+
+def hit_points(o, d, t):
+    """P = o + t·d for hit records (host side of the wavefront: where secondary rays start)."""
+    return o + t[:, None] * d
+
+
+def ao_rays(P, N, spp, radius=2.0, offset=1e-4, seed=1):
+    """C4: spp cosine-weighted hemisphere rays per hit point (the reference's AO, shader.cpp:140-232,
+    draws its directions from an unseeded RNG, so only the construction is mirrored: origin P + offset·dir,
+    occluded ⇔ a hit closer than `radius`).  Returns (o, d, tmax) with spp consecutive rays per point."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = len(P)
+    u1 = rng.random((n, spp)); u2 = rng.random((n, spp))
+    r = np.sqrt(u1); phi = 2.0 * np.pi * u2
+    x = r * np.cos(phi); y = r * np.sin(phi); z = np.sqrt(np.maximum(0.0, 1.0 - u1))
+    # orthonormal frame around N
+    a = np.where(np.abs(N[:, :1]) > 0.9, np.array([[0.0, 1.0, 0.0]]), np.array([[1.0, 0.0, 0.0]]))
+    T = np.cross(N, a); T /= np.linalg.norm(T, axis=1)[:, None]
+    B = np.cross(N, T)
+    d = x[..., None] * T[:, None, :] + y[..., None] * B[:, None, :] + z[..., None] * N[:, None, :]
+    d /= np.linalg.norm(d, axis=2)[..., None]
+    o = P[:, None, :] + offset * d
+    return o.reshape(-1, 3), d.reshape(-1, 3), np.full(n * spp, radius)
+
+
+def soft_shadow_rays(P, light_center, spp, half=1.0, offset=0.05, seed=2):
+    """C4: spp rays per hit point towards jittered points of a 2·half square through the light centre (the
+    reference's 25×4 grid on a 2×2 square, shader.cpp:55-91: origin P + 0.05·dir); tmax = distance to the sample."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = len(P)
+    j = rng.uniform(-half, half, (n, spp, 2))
+    L = np.empty((n, spp, 3))
+    L[..., 0] = light_center[0] + j[..., 0]
+    L[..., 1] = light_center[1] + j[..., 1]
+    L[..., 2] = light_center[2]
+    v = L - P[:, None, :]
+    dist = np.linalg.norm(v, axis=2)
+    d = v / dist[..., None]
+    o = P[:, None, :] + offset * d
+    return o.reshape(-1, 3), d.reshape(-1, 3), (dist - offset).reshape(-1)
