@@ -70,10 +70,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    # RTMI_DIST_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks share devices,
+    # collectives staged through the host): a correctness rehearsal, never a measurement.
+    backend = os.environ.get("RTMI_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         torch.cuda.synchronize()
@@ -84,7 +91,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -270,7 +277,8 @@ def main():
             "metric": "closest-hit Mrays/s on 1M-tri scene; form-factor+solve time @64K patches",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 (triangle test) + f32 (box tests)", "data": "synthetic",
+            "dtype": "f64 (triangle test) + f32 (box tests)",
+            "data": "synthetic" if backend == "nccl" else "synthetic (REHEARSAL over %s, ranks share GPUs: not a measurement)" % backend,
             "config": {"workload": "C3: %d-triangle random soup, %dx%d primary rays x %d spp (1 spp per GPU), closest hit" % (
                            args.tris, x_res, y_res, spp),
                        "rays_per_step": rays_total, "tiles": "%dx%d round-robin over ranks" % TILE,

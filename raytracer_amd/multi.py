@@ -52,6 +52,7 @@ def solve_sharded(sweep, E, n, tol_rel=1e-7, max_sweeps=1000, check_every=4, gro
     row0, n_rows, blk = rows_of_rank(n, rank, world)
     n_pad = blk * world
     dev = E.device
+    staged = world > 1 and E.is_cuda and dist.get_backend(group) == "gloo"
     B = torch.zeros((n_pad, 3), dtype=torch.float32, device=dev)
     B[:n] = E                                                  # B_0 = E, Render2/radiosity.cpp:506-509
     Bn = torch.zeros_like(B)
@@ -62,7 +63,13 @@ def solve_sharded(sweep, E, n, tol_rel=1e-7, max_sweeps=1000, check_every=4, gro
         sweep(B, Bn, norms)
         if world > 1:
             # every rank contributes its block of rows (blk·3 floats: 96 KiB at 64 K patches on 8 GPUs)
-            dist.all_gather_into_tensor(Bn.view(-1), Bn[rank * blk:(rank + 1) * blk].reshape(-1).clone(), group=group)
+            mine = Bn[rank * blk:(rank + 1) * blk].reshape(-1).clone()
+            if staged:   # rehearsal only: gloo cannot gather device tensors, go through the host
+                parts = [torch.empty(blk * 3, dtype=torch.float32) for _ in range(world)]
+                dist.all_gather(parts, mine.cpu(), group=group)
+                Bn.view(-1).copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(Bn.view(-1), mine, group=group)
         B, Bn = Bn, B
         sweeps += 1
         if after_sweep is not None:
@@ -70,6 +77,8 @@ def solve_sharded(sweep, E, n, tol_rel=1e-7, max_sweeps=1000, check_every=4, gro
         if sweeps % check_every == 0 or sweeps == max_sweeps:
             if world > 1:
                 s = norms[:2].clone(); m = norms[2:].clone()
+                if staged:
+                    s, m = s.cpu(), m.cpu()
                 dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
                 dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
                 h = torch.cat([s, m]).cpu()
