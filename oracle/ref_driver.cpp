@@ -15,6 +15,7 @@
 #include "ray_tracer.h"
 #include "util.h"
 #include "radiosity_helper.h"
+#include "ref_scene.h"
 
 #include <chrono>
 #include <cstdint>
@@ -41,14 +42,6 @@ extern vector<ObjectNode *> radObjectNodes;      // radiosity.cpp:8
 extern "C" void ref_raster_details_impl(Scene *scene, Camera *cam, double *out18);
 
 namespace {
-
-struct RefScene {
-	Scene scene;
-	Camera cam;
-	Radiosity *rad = nullptr;
-	std::vector<QuadTreeNode *> elems;
-	bool bsp_built = false;
-};
 
 inline Vec3 V(const double *p) { return Vec3(p[0], p[1], p[2]); }
 inline void put(double *p, const Vec3 &a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
