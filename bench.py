@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--tris", type=int, default=1 << 20)
     ap.add_argument("--res", default="3840x2160")
     ap.add_argument("--patches", type=int, default=65536)
-    ap.add_argument("--ff-rows", type=int, default=128, help="rows of the 64K-patch form-factor matrix to build (sample)")
+    ap.add_argument("--ff-rows", type=int, default=-1, help="-1: build the whole 64K-patch form-factor matrix and solve on it; K>0: a sample of K rows; 0: skip")
     ap.add_argument("--no-solver", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
@@ -226,25 +226,55 @@ def main():
         del F
         torch.cuda.empty_cache()
 
-        # (c) form-factor build rate at 64 K patches: closed box with 12·74² = 65 712 patches, a sample of rows
-        if args.ff_rows > 0:
+        # (c) form factors at 64 K patches: box with 12·74² − (ceiling opening) patches, light above the opening.
+        #     --ff-rows -1 (default): this rank's whole row block, in launches of 4096 rows, then the solve on that
+        #     real F; --ff-rows K > 0: a sample of K rows only (extrapolated, marked as such).
+        if args.ff_rows != 0:
             k = max(1, int(round((n / 12.0) ** 0.5)))
-            verts, normals, light = workloads.closed_box(k)
+            verts, normals, light = workloads.closed_box(k, hole=0.3)
             box = rt.Scene(verts)
             rad = rt.Radiosity(box, normals, light)
-            r0, nr, _ = multi.rows_of_rank(rad.n, rank, world)
-            nr_s = min(args.ff_rows, nr)
-            rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=r0, n_rows=min(8, nr_s))   # warm-up
+            nb = rad.n
+            ldb = (nb + 3) // 4 * 4
+            r0, nr, _ = multi.rows_of_rank(nb, rank, world)
+            full = args.ff_rows < 0
+            nr_s = nr if full else min(args.ff_rows, nr)
+            Fb = torch.empty((nr_s, ldb), dtype=torch.float32, device="cuda")
+            lc = np.ascontiguousarray(light, np.float64)
+
+            def build(first, count):
+                rc = rt.lib.rtmi_form_factors_dev(rad.handle, lc.ctypes.data, 10, 30, 1, 0, r0 + first, count,
+                                                  Fb[first:].data_ptr(), ldb, stream)
+                if rc != 0:
+                    raise SystemExit(rt.lib.rtmi_last_error().decode())
+            build(0, min(8, nr_s))                                                   # warm-up
             barrier()
             t0 = time.perf_counter()
-            rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=r0, n_rows=nr_s)
+            for first in range(0, nr_s, 4096):
+                build(first, min(4096, nr_s - first))
             barrier()
             ff_s = max_over_ranks(time.perf_counter() - t0)
-            vis_rays = 10.0 * nr_s * (rad.n - 2) * world
+            vis_rays = 10.0 * (rad.numOfElements - 1) * (nb - 1 if full else nr_s * world)
             formfactor = {"patches": rad.numOfElements, "rows_built_per_rank": nr_s, "seconds": round(ff_s, 4),
-                          "visibility_Mrays_per_s": round(vis_rays / ff_s / 1e6, 1),
-                          "extrapolated_full_build_seconds": round(ff_s * nr / nr_s, 1),
-                          "note": "sample of rows; every row costs the same number of visibility rays"}
+                          "visibility_Mrays_per_s": round(vis_rays / ff_s / 1e6, 1), "samples_per_pair": 10,
+                          "full_matrix": full, "F_GiB_per_rank": round(nr_s * ldb * 4 / 2**30, 2)}
+            if not full:
+                formfactor["extrapolated_full_build_seconds"] = round(ff_s * nr / nr_s, 1)
+            else:
+                # the solve on the F just built (the metric's "form-factor + solve time")
+                rad.FF, rad.ld, rad.row0, rad.n_rows = Fb, ldb, r0, nr
+                barrier()
+                t0 = time.perf_counter()
+                rad.progressiveRefinement(tol_rel=1e-4, max_sweeps=1000, check_every=4)
+                barrier()
+                sv = max_over_ranks(time.perf_counter() - t0)
+                Bh = rad.B[: rad.numOfElements, 0].float().cpu().numpy()
+                formfactor.update({"solve_seconds": round(sv, 4), "solve_sweeps": int(rad.stats.sweeps),
+                                   "solve_rel_change": rad.stats.rel_change, "formfactor_plus_solve_seconds": round(ff_s + sv, 3),
+                                   "B_mean": float(Bh.mean()), "B_max": float(Bh.max()),
+                                   "row_sum_mean_of_local_rows": float(Fb[:, : rad.numOfElements].sum(1).mean())})
+            del Fb
+            rad.FF = None
             rad.close(); box.close()
 
     # ------------------------------------------------------------------ CPU baseline (oracle), rank 0, N = 1
