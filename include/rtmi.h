@@ -30,7 +30,9 @@ extern "C" {
 #define RTMI_MISS 0xFFFFFFFFu
 #define RTMI_INFINITY 1.0e20 /* Render2/base.h:56 — "no tmax" */
 
-/* Render2/ray.h:23-32 (origin, unit direction); tmax <= 0 or >= 1e20 means 1e20. 64 bytes. */
+/* Render2/ray.h:23-32 (origin, unit direction); tmax <= 0 or >= 1e20 means 1e20.  reserved: 0 = a ray;
+ * anything else = an inactive slot of a wavefront (answered with a miss / not occluded, nothing is traced) —
+ * the generators below write it for pixels whose primary ray hit nothing.  64 bytes. */
 typedef struct rtmi_ray {
 	double o[3];
 	double d[3];
@@ -120,6 +122,23 @@ int rtmi_primary_work_dev(rtmi_scene *, const rtmi_camera *cam, double sx, doubl
  * occluded[k] = 1 iff some triangle has 0 < t < tmax. */
 int rtmi_any_hit(rtmi_scene *, const rtmi_ray *rays, uint64_t n, uint8_t *occluded);
 int rtmi_any_hit_dev(rtmi_scene *, const rtmi_ray *d_rays, uint64_t n, uint8_t *d_occluded, void *stream);
+
+/* ---- wavefront: secondary rays generated on the device -----------------------------------------------
+ * The batch producers between two ray-query calls, so that a frame's hit records never leave HBM:
+ * d_rays[k] produced d_hits[k]; d_normals = n_tris × 3 doubles, the reference's triNormal per ORIGINAL triangle
+ * (device pointer).  The hit point is the reference's plane formula (Render2/object.cpp:23).  Slots whose
+ * hit is a miss are written as inactive rays.
+ *   rtmi_shadow_rays_dev   Shader::generateNormalShadows (Render2/shader.cpp:116-127): origin P + 0.01·normal,
+ *                          direction Unit(light_center − P); ask rtmi_any_hit_dev (shader.cpp:131)
+ *   rtmi_ao_rays_dev       Shader::findOcclusionNew (Render2/shader.cpp:140-232): spp rays per hit, ray k·spp+s
+ *                          from the square point of stream (seed, k, s) — the reference draws it from an unseeded
+ *                          mt19937 —, origin P + 1e-4·dir, tmax = radius (occluded ⇔ Cast ∧ distance < radius, :226)
+ *   rtmi_occlusion_fraction_dev   1 − occlusions/spp per hit (shader.cpp:231) from the any-hit bytes */
+int rtmi_shadow_rays_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                         const double light_center[3], rtmi_ray *d_out, void *stream);
+int rtmi_ao_rays_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                     uint32_t spp, double radius, uint64_t seed, rtmi_ray *d_out, void *stream);
+int rtmi_occlusion_fraction_dev(const uint8_t *d_occluded, uint64_t n, uint32_t spp, double *d_out, void *stream);
 
 /* ---- radiosity: form factors ------------------------------------------------------------------------
  * The patches are the scene's triangles (elements = the leaves every visibility ray is tested

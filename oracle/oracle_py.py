@@ -91,6 +91,19 @@ class Oracle:
         self.lib.rto_shadow_rays(C.c_long(len(P)), _p(P), _p(N), _p(Cc), _p(o), _p(d))
         return o, d
 
+    def ao_rays(self, P, N, R, spp, seed):
+        P = _f64(P, (-1, 3)); N = _f64(N, (-1, 3))
+        n = len(P)
+        o = np.zeros((n * spp, 3)); d = np.zeros((n * spp, 3))
+        self.lib.rto_ao_rays(C.c_long(n), _p(P), _p(N), C.c_double(R), C.c_uint32(spp), C.c_uint64(seed), _p(o), _p(d))
+        return o, d
+
+    def ao_rays_points(self, P, N, R, ab):
+        P = _f64(P, (-1, 3)); N = _f64(N, (-1, 3)); ab = _f64(ab, (-1, 2))
+        o = np.zeros_like(P); d = np.zeros_like(P)
+        self.lib.rto_ao_rays_points(C.c_long(len(P)), _p(P), _p(N), C.c_double(R), _p(ab), _p(o), _p(d))
+        return o, d
+
     def area(self, verts):
         verts = _f64(verts, (-1, 9))
         return np.array([self.lib.rto_area(_p(v[0:3]), _p(v[3:6]), _p(v[6:9])) for v in verts])
@@ -262,6 +275,12 @@ class Reference:
         ob = np.zeros(n, np.int32); bu = np.zeros(n, np.float32); bv = np.zeros(n, np.float32)
         secs = self.lib.ref_cast(h, C.c_long(n), _p(o), _p(d), _p(hit), _p(dist), _p(pt), _p(nr), _p(ob), _p(bu), _p(bv))
         return dict(hit=hit, dist=dist, point=pt, normal=nr, obj=ob, bu=bu, bv=bv, seconds=secs)
+
+    def ao_occlusion(self, h, P, N, radius, nrays):
+        P = _f64(P, (-1, 3)); N = _f64(N, (-1, 3))
+        out = np.zeros(len(P))
+        self.lib.ref_ao_occlusion(h, C.c_long(len(P)), _p(P), _p(N), C.c_double(radius), C.c_int(nrays), _p(out))
+        return out
 
     def brute(self, h, o, d):
         o = _f64(o, (-1, 3)); d = _f64(d, (-1, 3)); n = len(o)

@@ -227,6 +227,21 @@ double ref_cast(void *h, long n, const double *o, const double *d, uint8_t *hit,
 	return now_s() - t0;
 }
 
+// Shader::findOcclusionNew (shader.cpp:140-232) at n surface points: out[k] = 1 − occlusions/nrays.  The reference
+// seeds its mt19937 from std::random_device inside the call, so the value is a Monte-Carlo estimate; callers
+// average many rays.  Needs ref_build_bsp (it calls Scene::Cast).
+void ref_ao_occlusion(void *h, long n, const double *P, const double *N, double radius, int nrays, double *out) {
+	RefScene *s = (RefScene *)h;
+	Shader sh;
+	for (long k = 0; k < n; ++k) {
+		HitInfo hit;
+		hit.point = V(P + 3 * k);
+		hit.normal = V(N + 3 * k);
+		Color c;
+		out[k] = sh.findOcclusionNew(s->scene, hit, c, radius, nrays);
+	}
+}
+
 // Brute force with the reference's triangle_intersection over the ORIGINAL triangles in
 // flattened order, keeping the strict minimum of the positive t (first wins on ties) —
 // the semantics of intersectTreeTraversalNoAccel (object.cpp:143-168) + Scene::Cast's

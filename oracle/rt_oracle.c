@@ -157,6 +157,68 @@ void rto_shadow_rays(long n, const double *P, const double *N, const double C[3]
 	}
 }
 
+static inline uint64_t mix64(uint64_t z);
+/* shader.cpp:140-232 findOcclusionNew: the hemisphere frame and the AO ray of one square point (a, b) in
+ * [-1,1)^2 (the reference draws a, b from an unseeded mt19937, :148-150,177; here they are injected).
+ * Returns direction (unit) and origin P + dir·1e-4. */
+static void ao_frame(v3 normal, v3 *X, v3 *Y, v3 *Z) {
+	*Z = unit(normal);                                   /* :153 */
+	v3 t = *Z;
+	double cz = fabs(Z->z), cx = fabs(Z->x), cy = fabs(Z->y);
+	if (cz <= cx) {                                      /* :160-168, the reference's own branch structure */
+		if (cz <= cy) t.z = 1;
+	} else if (cx <= cz) {
+		if (cx <= cy) t.x = 1;
+	} else t.y = 1;
+	*X = unit(cross(t, *Z));                             /* :170 */
+	*Y = cross(*Z, *X);                                  /* :171 */
+}
+static void ao_ray(v3 P, v3 X, v3 Y, v3 Z, double R, double a, double b, v3 *o, v3 *d) {
+	double phi, r;
+	if (a > -b) {                                        /* :182-204 square -> disc */
+		if (a > b) { r = a; phi = (RTO_PI / 4.0) * (b / a); }
+		else { r = b; phi = (RTO_PI / 4.0) * (2.0 - (a / b)); }
+	} else {
+		if (a < b) { r = -a; phi = (RTO_PI / 4.0) * (4.0 + (b / a)); }
+		else { r = -b; phi = (b != 0) ? (RTO_PI / 4.0) * (6.0 - (a / b)) : 0; }
+	}
+	double u = r * cos(phi), v = r * sin(phi);           /* :206-207 */
+	v3 base = add(scl(u, X), scl(v, Y));                 /* :210-211 */
+	double leg = (R * R) - (len(base) * len(base));      /* :212 */
+	v3 dir = unit(add(scl(leg / R, Z), base));           /* :214,218 */
+	*d = dir;
+	*o = add(P, scl(.0001, dir));                        /* :220 */
+}
+void rto_ao_square_point(uint64_t seed, uint64_t ray, uint32_t sample, double ab[2]) {
+	uint64_t h = mix64(mix64(seed ^ ray) ^ (uint64_t)sample);
+	ab[0] = (2.0 * ((double)(h >> 11) * 0x1.0p-53)) - 1.0;          /* dis(gen) - 1, dis = uniform(0,2): :150,177 */
+	ab[1] = (2.0 * ((double)(mix64(h) >> 11) * 0x1.0p-53)) - 1.0;
+}
+void rto_ao_rays(long n, const double *P, const double *N, double R, uint32_t spp, uint64_t seed, double *o, double *d) {
+	for (long k = 0; k < n; ++k) {
+		v3 X, Y, Z;
+		ao_frame(ld3(N + 3 * k), &X, &Y, &Z);
+		for (uint32_t s = 0; s < spp; ++s) {
+			double ab[2];
+			rto_ao_square_point(seed, (uint64_t)k, s, ab);
+			v3 oo, dd;
+			ao_ray(ld3(P + 3 * k), X, Y, Z, R, ab[0], ab[1], &oo, &dd);
+			st3(o + 3 * ((long)k * spp + s), oo);
+			st3(d + 3 * ((long)k * spp + s), dd);
+		}
+	}
+}
+/* same construction on injected square points: m rays, frame from N[k], point (a,b) = ab[2k..] */
+void rto_ao_rays_points(long m, const double *P, const double *N, double R, const double *ab, double *o, double *d) {
+	for (long k = 0; k < m; ++k) {
+		v3 X, Y, Z, oo, dd;
+		ao_frame(ld3(N + 3 * k), &X, &Y, &Z);
+		ao_ray(ld3(P + 3 * k), X, Y, Z, R, ab[2 * k], ab[2 * k + 1], &oo, &dd);
+		st3(o + 3 * k, oo);
+		st3(d + 3 * k, dd);
+	}
+}
+
 /* ---- radiosity -------------------------------------------------------------- */
 double rto_area(const double a[3], const double b[3], const double c[3]) {
 	return len(cross(sub(ld3(b), ld3(a)), sub(ld3(c), ld3(a)))) / 2.0;

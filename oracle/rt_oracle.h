@@ -57,6 +57,13 @@ void rto_hit_point(const double o[3], const double d[3], const double v1[3], con
 /* shader.cpp:116-127: shadow ray origin P + 0.01·n, direction Unit(C − P) */
 void rto_shadow_rays(long n, const double *P, const double *N, const double C[3], double *o, double *d);
 
+/* shader.cpp:140-232 (findOcclusionNew): spp AO rays per point; ray k·spp+s uses the square point
+ * rto_ao_square_point(seed, k, s) where the reference draws from an unseeded mt19937.  Origin P + 1e-4·dir;
+ * the caller asks "hit closer than R" (shader.cpp:226). */
+void rto_ao_square_point(uint64_t seed, uint64_t ray, uint32_t sample, double ab[2]);
+void rto_ao_rays(long n, const double *P, const double *N, double R, uint32_t spp, uint64_t seed, double *o, double *d);
+void rto_ao_rays_points(long m, const double *P, const double *N, double R, const double *ab, double *o, double *d);
+
 /* ---- radiosity ---------------------------------------------------------- */
 /* patches: n × 9 doubles (v1,v2,v3) + normals n × 3 (the reference's triNormal).  The
  * patches are also the occluders (elements = the BSP leaves every ray is tested against). */

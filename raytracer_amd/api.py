@@ -56,7 +56,8 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_
 SYMBOLS = [
     "rtmi_last_error", "rtmi_device_count", "rtmi_triangle_intersection", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_get_info",
     "rtmi_closest_hit", "rtmi_closest_hit_dev", "rtmi_camera_setup", "rtmi_primary_closest_hit_dev",
-    "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
+    "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev",
+    "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev",
 ]
 
@@ -82,6 +83,9 @@ def _load():
     L.rtmi_primary_closest_hit_dev.argtypes = [vp, C.POINTER(rtmi_camera), dbl, dbl, u32, u32, u32, u32, vp, vp]
     L.rtmi_primary_rays_dev.argtypes = [C.POINTER(rtmi_camera), dbl, dbl, vp, vp]
     L.rtmi_primary_work_dev.argtypes = [vp, C.POINTER(rtmi_camera), dbl, dbl, vp, vp]
+    L.rtmi_shadow_rays_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
+    L.rtmi_ao_rays_dev.argtypes = [vp, vp, vp, vp, u64, u32, dbl, u64, vp, vp]
+    L.rtmi_occlusion_fraction_dev.argtypes = [vp, u64, u32, vp, vp]
     L.rtmi_patches_create.restype = vp
     L.rtmi_patches_create.argtypes = [vp, vp, vp]
     L.rtmi_patches_destroy.argtypes = [vp]
@@ -225,9 +229,24 @@ class Scene:
                                                 tile_stride, d_out, stream))
 
 
+    # -- wavefront stages (device buffers): secondary rays from hit records --
+    def shadow_rays_dev(self, d_normals, d_rays, d_hits, n, light_center, d_out, stream=0):
+        """Shader::generateNormalShadows' ray (shader.cpp:116-127) for every hit record."""
+        lc = _np(light_center, np.float64, (3,))
+        _check(lib.rtmi_shadow_rays_dev(self.handle, d_normals, d_rays, d_hits, n, _ptr(lc), d_out, stream))
+
+    def ao_rays_dev(self, d_normals, d_rays, d_hits, n, spp, radius, seed, d_out, stream=0):
+        """Shader::findOcclusionNew's rays (shader.cpp:140-232), spp per hit record."""
+        _check(lib.rtmi_ao_rays_dev(self.handle, d_normals, d_rays, d_hits, n, spp, float(radius), seed, d_out, stream))
+
     def primary_work_dev(self, cam, d_counts, sx=0.5, sy=0.5, stream=0):
         """Diagnostic: adds (node visits, triangle tests) of the frame's primary rays to d_counts[0..1] (uint64)."""
         _check(lib.rtmi_primary_work_dev(self.handle, C.byref(cam.c), sx, sy, d_counts, stream))
+
+
+def occlusion_fraction_dev(d_occluded, n, spp, d_out, stream=0):
+    """1 − occlusions/spp per hit (shader.cpp:231)."""
+    _check(lib.rtmi_occlusion_fraction_dev(d_occluded, n, spp, d_out, stream))
 
 
 def primary_rays_dev(cam, d_rays, sx=0.5, sy=0.5, stream=0):

@@ -11,12 +11,14 @@ struct rtmi_scene {
 	int device;
 	uint32_t stack_bytes; // dynamic LDS of every traversal kernel: (BVH depth + 1) ints per lane
 	rtmi_scene_info info;
+	double *d_v1_orig; // n_tris × 3: triVert1 of every triangle in ORIGINAL order (hit points, object.cpp:23)
 };
 
 namespace rtmi {
 extern thread_local std::string g_err;
 int fail(const std::string &msg);        // records msg for rtmi_last_error(), returns -1
 int launch_check(const char *who);
+int check_scene(const rtmi_scene *s, const char *who); // NULL / wrong current device -> -1
 unsigned env_uint(const char *name, unsigned dflt); // tuning overrides from the environment
 Tune refill_threshold();                          // RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF       // hipGetLastError() after a launch -> 0 / -1
 } // namespace rtmi

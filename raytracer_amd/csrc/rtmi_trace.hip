@@ -42,6 +42,11 @@ RTMI_TRAVERSAL_KERNEL void k_trace_rays(SceneDev S, uint32_t stack_bytes, const 
 	const uint32_t items = (uint32_t)(n - base < (uint64_t)chunk ? n - base : (uint64_t)chunk);
 	auto fetch = [&](uint32_t idx, RayD &R) {
 		const rtmi_ray q = rays[base + idx];
+		if (q.reserved != 0.0) { // an inactive slot of a wavefront (e.g. the shadow ray of a pixel that hit nothing)
+			if (ANY) occluded[base + idx] = 0;
+			else { rtmi_hit o; o.t = 0.0; o.u = o.v = 0.f; o.tri = o.object = RTMI_MISS; out[base + idx] = o; }
+			return false;
+		}
 		R.ox = q.o[0]; R.oy = q.o[1]; R.oz = q.o[2];
 		R.dx = q.d[0]; R.dy = q.d[1]; R.dz = q.d[2];
 		double tmax = q.tmax;
@@ -212,6 +217,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	std::memcpy(s->info.scene_hi, bvh.hi, sizeof bvh.hi);
 	if (hipGetDevice(&s->device) != hipSuccess) { delete s; fail("hipGetDevice failed"); return nullptr; }
 	s->dev.nodes = nullptr; s->dev.tris = nullptr; s->dev.root_ref = kSentinel; s->dev.absmax = 0.f;
+	s->d_v1_orig = nullptr;
 	// one push per inner node on a root-to-leaf path at most: depth entries, +1 spare
 	s->stack_bytes = (bvh.depth + 1u) * kBlock * (uint32_t)sizeof(int);
 	if (n == 0) return s;
@@ -266,11 +272,17 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	float absmax = 0.f;
 	for (int a = 0; a < 3; ++a) absmax = std::max(absmax, std::max(std::fabs(bvh.lo[a]), std::fabs(bvh.hi[a])));
 
+	std::vector<double> v1(3 * n);
+	for (uint64_t k = 0; k < n; ++k)
+		for (int a = 0; a < 3; ++a) v1[3 * k + a] = xyz[9 * k + a];
 	GNode *d_nodes = nullptr;
 	GTri *d_tris = nullptr;
 	const size_t nb = std::max<size_t>(1, nodes.size()) * sizeof(GNode), tb = tris.size() * sizeof(GTri);
-	if (hipMalloc(&d_nodes, nb) != hipSuccess || hipMalloc(&d_tris, tb) != hipSuccess) {
+	if (hipMalloc(&d_nodes, nb) != hipSuccess || hipMalloc(&d_tris, tb) != hipSuccess ||
+	    hipMalloc(&s->d_v1_orig, v1.size() * sizeof(double)) != hipSuccess) {
 		if (d_nodes) (void)hipFree(d_nodes);
+		if (d_tris) (void)hipFree(d_tris);
+		if (s->d_v1_orig) (void)hipFree(s->d_v1_orig);
 		delete s;
 		fail("rtmi_scene_create: hipMalloc failed");
 		return nullptr;
@@ -278,20 +290,21 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	bool ok = true;
 	if (!nodes.empty()) ok = ok && hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(GNode), hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(d_tris, tris.data(), tb, hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && hipMemcpy(s->d_v1_orig, v1.data(), v1.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
 	if (!ok) {
-		(void)hipFree(d_nodes); (void)hipFree(d_tris);
+		(void)hipFree(d_nodes); (void)hipFree(d_tris); (void)hipFree(s->d_v1_orig);
 		delete s;
 		fail("rtmi_scene_create: upload failed");
 		return nullptr;
 	}
 	s->dev.nodes = d_nodes; s->dev.tris = d_tris; s->dev.root_ref = root_ref; s->dev.absmax = absmax;
 	s->info.n_nodes = nodes.size();
-	s->info.device_bytes = nb + tb;
+	s->info.device_bytes = nb + tb + v1.size() * sizeof(double);
 	s->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	return s;
 }
 
-static int check_scene(const rtmi_scene *s, const char *who) {
+int check_scene(const rtmi_scene *s, const char *who) {
 	if (!s) return fail(std::string(who) + ": scene is NULL");
 	int dev = -1;
 	if (hipGetDevice(&dev) != hipSuccess) return fail(std::string(who) + ": hipGetDevice failed");
@@ -363,6 +376,7 @@ void rtmi_scene_destroy(rtmi_scene *s) {
 	if (!s) return;
 	if (s->dev.nodes) (void)hipFree((void *)s->dev.nodes);
 	if (s->dev.tris) (void)hipFree((void *)s->dev.tris);
+	if (s->d_v1_orig) (void)hipFree(s->d_v1_orig);
 	delete s;
 }
 

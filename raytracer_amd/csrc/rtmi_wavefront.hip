@@ -1,0 +1,158 @@
+// librtmi — the secondary-ray generators of the wavefront: the batch producers that sit between two ray-query
+// calls so that a frame never leaves the device (primary hits -> shadow / ambient-occlusion rays -> any-hit).
+// Reference: Render2/shader.cpp (generateNormalShadows :105-138, findOcclusionNew :140-232), all in double in the
+// reference's operation order.  gfx950 only.
+#include "rtmi_host.hpp"
+
+namespace rtmi {
+
+constexpr double kPiRef = 3.14159265358979; // Render2/base.h:52
+
+__device__ __forceinline__ D3 cross(D3 a, D3 b) { // vec3.h:50
+	return d3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ uint64_t wf_mix64(uint64_t z) {
+	z += 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+// hit.point of updateHitInfo (object.cpp:23): origin + (direction·((triVert1 − origin)·n)) / (n·direction)
+__device__ __forceinline__ D3 hit_point(const rtmi_ray &r, const double *v1, D3 n) {
+	const D3 o = d3(r.o[0], r.o[1], r.o[2]), d = d3(r.d[0], r.d[1], r.d[2]);
+	return o + (dot(d3(v1[0], v1[1], v1[2]) - o, n) * d) / dot(n, d);
+}
+
+__device__ __forceinline__ void inactive(rtmi_ray &q) {
+	q.o[0] = q.o[1] = q.o[2] = 0.0;
+	q.d[0] = q.d[1] = 0.0; q.d[2] = 1.0;
+	q.tmax = RTMI_INFINITY;
+	q.reserved = 1.0;
+}
+
+// generateNormalShadows (shader.cpp:116-127): origin P + 0.01·normal, direction Unit(C − P)
+__global__ void k_shadow_rays(const double *__restrict__ v1_orig, const double *__restrict__ normals,
+                              const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits, uint64_t n, double cx,
+                              double cy, double cz, rtmi_ray *__restrict__ out) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	rtmi_ray q;
+	const rtmi_hit h = hits[k];
+	if (h.tri == RTMI_MISS) {
+		inactive(q);
+	} else {
+		const D3 nrm = d3(normals[3 * (size_t)h.tri], normals[3 * (size_t)h.tri + 1], normals[3 * (size_t)h.tri + 2]);
+		const D3 P = hit_point(rays[k], v1_orig + 3 * (size_t)h.tri, nrm);
+		const D3 dir = unit(d3(cx, cy, cz) - P);
+		const D3 org = P + (0.01 * nrm);
+		q.o[0] = org.x; q.o[1] = org.y; q.o[2] = org.z;
+		q.d[0] = dir.x; q.d[1] = dir.y; q.d[2] = dir.z;
+		q.tmax = RTMI_INFINITY;
+		q.reserved = 0.0;
+	}
+	out[k] = q;
+}
+
+// findOcclusionNew (shader.cpp:140-232): one lane per (hit, sample); the square point the reference draws from an
+// unseeded mt19937 (:148-150,177) comes from the counter-based stream (seed, ray index, sample).
+__global__ void k_ao_rays(const double *__restrict__ v1_orig, const double *__restrict__ normals,
+                          const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits, uint64_t n, uint32_t spp,
+                          double R, uint64_t seed, rtmi_ray *__restrict__ out) {
+	const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= n * spp) return;
+	const uint64_t k = idx / spp;
+	const uint32_t s = (uint32_t)(idx % spp);
+	rtmi_ray q;
+	const rtmi_hit h = hits[k];
+	if (h.tri == RTMI_MISS) {
+		inactive(q);
+	} else {
+		const D3 nrm = d3(normals[3 * (size_t)h.tri], normals[3 * (size_t)h.tri + 1], normals[3 * (size_t)h.tri + 2]);
+		const D3 P = hit_point(rays[k], v1_orig + 3 * (size_t)h.tri, nrm);
+		const D3 Z = unit(nrm); // :153
+		D3 t = Z;
+		const double cz = fabs(Z.z), cx = fabs(Z.x), cy = fabs(Z.y);
+		if (cz <= cx) { // :160-168, the reference's own branch structure
+			if (cz <= cy) t.z = 1;
+		} else if (cx <= cz) {
+			if (cx <= cy) t.x = 1;
+		} else t.y = 1;
+		const D3 X = unit(cross(t, Z)); // :170
+		const D3 Y = cross(Z, X);       // :171
+		const uint64_t hsh = wf_mix64(wf_mix64(seed ^ k) ^ (uint64_t)s);
+		const double a = (2.0 * ((double)(hsh >> 11) * 0x1.0p-53)) - 1.0; // dis(gen) − 1, dis = uniform(0, 2)
+		const double b = (2.0 * ((double)(wf_mix64(hsh) >> 11) * 0x1.0p-53)) - 1.0;
+		double phi, r;
+		if (a > -b) { // :182-204
+			if (a > b) { r = a; phi = (kPiRef / 4.0) * (b / a); }
+			else { r = b; phi = (kPiRef / 4.0) * (2.0 - (a / b)); }
+		} else {
+			if (a < b) { r = -a; phi = (kPiRef / 4.0) * (4.0 + (b / a)); }
+			else { r = -b; phi = (b != 0) ? (kPiRef / 4.0) * (6.0 - (a / b)) : 0; }
+		}
+		const double u = r * cos(phi), v = r * sin(phi);               // :206-207
+		const D3 base = (u * X) + (v * Y);                             // :210-211
+		const double lb = sqrt(len2(base));
+		const double leg = (R * R) - (lb * lb);                        // :212
+		const D3 dir = unit(((leg / R) * Z) + base);                   // :214,218
+		const D3 org = P + (.0001 * dir);                              // :220
+		q.o[0] = org.x; q.o[1] = org.y; q.o[2] = org.z;
+		q.d[0] = dir.x; q.d[1] = dir.y; q.d[2] = dir.z;
+		q.tmax = R; // occluded ⇔ Cast ∧ distance < R (:226)
+		q.reserved = 0.0;
+	}
+	out[idx] = q;
+}
+
+// 1 − occlusions / spp per hit (shader.cpp:231)
+__global__ void k_occlusion_fraction(const uint8_t *__restrict__ occ, uint64_t n, uint32_t spp, double *__restrict__ out) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	int c = 0;
+	for (uint32_t s = 0; s < spp; ++s) c += occ[k * spp + s];
+	out[k] = (1.0 - (c / (double)spp));
+}
+
+} // namespace rtmi
+
+using namespace rtmi;
+
+extern "C" {
+
+int rtmi_shadow_rays_dev(rtmi_scene *s, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                         const double light_center[3], rtmi_ray *d_out, void *stream) {
+	const char *who = "rtmi_shadow_rays_dev";
+	if (check_scene(s, who)) return -1;
+	if (n == 0) return 0;
+	if (!d_normals || !d_rays || !d_hits || !light_center || !d_out) return fail(std::string(who) + ": NULL argument");
+	if (n > (uint64_t)0x7fffffff * 256) return fail(std::string(who) + ": too many rays for one launch");
+	hipLaunchKernelGGL(k_shadow_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->d_v1_orig, d_normals,
+	                   d_rays, d_hits, n, light_center[0], light_center[1], light_center[2], d_out);
+	return launch_check(who);
+}
+
+int rtmi_ao_rays_dev(rtmi_scene *s, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                     uint32_t spp, double radius, uint64_t seed, rtmi_ray *d_out, void *stream) {
+	const char *who = "rtmi_ao_rays_dev";
+	if (check_scene(s, who)) return -1;
+	if (n == 0 || spp == 0) return 0;
+	if (!d_normals || !d_rays || !d_hits || !d_out) return fail(std::string(who) + ": NULL argument");
+	if (!(radius > 0.0)) return fail(std::string(who) + ": radius must be positive");
+	const uint64_t total = n * spp;
+	if (total > (uint64_t)0x7fffffff * 256) return fail(std::string(who) + ": too many rays for one launch");
+	hipLaunchKernelGGL(k_ao_rays, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->d_v1_orig, d_normals,
+	                   d_rays, d_hits, n, spp, radius, seed, d_out);
+	return launch_check(who);
+}
+
+int rtmi_occlusion_fraction_dev(const uint8_t *d_occluded, uint64_t n, uint32_t spp, double *d_out, void *stream) {
+	const char *who = "rtmi_occlusion_fraction_dev";
+	if (n == 0) return 0;
+	if (!d_occluded || !d_out || spp == 0) return fail(std::string(who) + ": NULL argument or spp == 0");
+	hipLaunchKernelGGL(k_occlusion_fraction, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_occluded, n, spp,
+	                   d_out);
+	return launch_check(who);
+}
+
+} // extern "C"

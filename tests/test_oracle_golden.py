@@ -158,3 +158,24 @@ def test_g4_solver_matches_reference(oracle, stem):
 def test_g5_btxt_facts():
     f = json.load(open(os.path.join(GOLDEN, "g5_btxt_facts.json")))
     assert f["lines"] == 2609 and f["last_value"] == 68500.0
+
+
+def test_g3_ao_construction_statistics(oracle):
+    """Shader::findOcclusionNew (shader.cpp:140-232) seeds its RNG from std::random_device, so the fixture holds the
+    compiled reference's Monte-Carlo mean over 4000 rays at 48 surface points of scene_room_bed_sample; the
+    restated construction on seeded square points must agree within 5 standard errors."""
+    g = load_golden("g3_ao_room.npz")
+    room = load_golden("g2_scene_room_bed_sample.npz")
+    NR = int(g["nrays"])
+    o, d = oracle.ao_rays(g["P"], g["N"], float(g["radius"]), NR, 11)
+    occ = oracle.any_hit(room["tris"], o, d, np.full(len(o), float(g["radius"]))).reshape(len(g["P"]), NR).mean(1)
+    mine, ref = 1.0 - occ, g["ref_ao"]
+    se = np.sqrt(np.maximum(ref * (1 - ref), 1e-4) / NR) * np.sqrt(2.0)
+    assert np.all(np.abs(mine - ref) <= 5 * se + 1e-3), np.abs(mine - ref).max()
+    assert ref.min() < 0.5 and ref.max() == 1.0                      # the points cover open and occluded places
+    # the same construction from injected square points
+    ab = np.array([[0.3, -0.2], [-0.7, 0.1], [0.0, 0.0], [-0.5, -0.5]])
+    o2, d2 = oracle.ao_rays_points(np.tile(g["P"][:1], (4, 1)), np.tile(g["N"][:1], (4, 1)), 2.0, ab)
+    assert np.allclose(np.linalg.norm(d2, axis=1), 1.0, atol=1e-15)
+    assert np.allclose(o2 - g["P"][:1], 1e-4 * d2, atol=1e-18)
+    assert np.all(d2 @ g["N"][0] > 0)                                 # rays leave into the hemisphere of the normal
