@@ -143,13 +143,33 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDe
 // rows: in every step a lane loads one float4 of each of the kRows rows (kRows independent 16-B loads
 // in flight, 1 KiB per wave-instruction, rows streamed sequentially so HBM pages stay open) and the 12
 // matching floats of B (3 × float4, L1/L2 hits shared by the block's rows).  Accumulation in double.
-constexpr int kRows = 8;
+#ifndef RTMI_JROWS
+#define RTMI_JROWS 8
+#endif
+#ifndef RTMI_JNT
+#define RTMI_JNT 1
+#endif
+#ifndef RTMI_JBLOCK
+#define RTMI_JBLOCK 256
+#endif
+constexpr int kRows = RTMI_JROWS;
+constexpr int kJBlock = RTMI_JBLOCK, kJWaves = RTMI_JBLOCK / 64;
+static_assert(kRows * 3 <= 32, "the final reduction runs over the first 32 lanes of wave 0");
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_F4(const float *p) {
+#if RTMI_JNT
+	const v4f x = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p)); // F is streamed once per sweep
+	return make_float4(x.x, x.y, x.z, x.w);
+#else
+	return *reinterpret_cast<const float4 *>(p);
+#endif
+}
 
-__global__ __launch_bounds__(kBlock) void k_jacobi_sweep(const float *__restrict__ F, uint64_t ld, uint32_t n, uint32_t row0,
+__global__ __launch_bounds__(kJBlock) void k_jacobi_sweep(const float *__restrict__ F, uint64_t ld, uint32_t n, uint32_t row0,
                                                          uint32_t n_rows, double rho0, double rho1, double rho2,
                                                          const float *__restrict__ E, const float *__restrict__ Bold,
                                                          float *__restrict__ Bnew, double *__restrict__ norms) {
-	__shared__ double red[4][kRows][3];
+	__shared__ double red[kJWaves][kRows][3];
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const uint32_t r0 = blockIdx.x * kRows; // local row
 	double acc[kRows][3];
@@ -159,10 +179,10 @@ __global__ __launch_bounds__(kBlock) void k_jacobi_sweep(const float *__restrict
 #pragma unroll
 	for (int r = 0; r < kRows; ++r) rowp[r] = F + (uint64_t)min(r0 + r, n_rows - 1) * ld; // tail rows re-read the last row
 	const uint32_t n4 = n & ~3u;
-	for (uint32_t c = (wave * 64 + lane) * 4; c < n4; c += 4 * kBlock) {
+	for (uint32_t c = (wave * 64 + lane) * 4; c < n4; c += 4 * kJBlock) {
 		float4 f[kRows];
 #pragma unroll
-		for (int r = 0; r < kRows; ++r) f[r] = *reinterpret_cast<const float4 *>(rowp[r] + c);
+		for (int r = 0; r < kRows; ++r) f[r] = load_F4(rowp[r] + c);
 		const float4 b0 = *reinterpret_cast<const float4 *>(Bold + 3 * (size_t)c);
 		const float4 b1 = *reinterpret_cast<const float4 *>(Bold + 3 * (size_t)c + 4);
 		const float4 b2 = *reinterpret_cast<const float4 *>(Bold + 3 * (size_t)c + 8);
@@ -204,7 +224,9 @@ __global__ __launch_bounds__(kBlock) void k_jacobi_sweep(const float *__restrict
 		const uint32_t r = lane / 3, ch = lane % 3;
 		double d2 = 0.0, b2 = 0.0, dmax = 0.0;
 		if (lane < kRows * 3 && r0 + r < n_rows) {
-			const double s = red[0][r][ch] + red[1][r][ch] + red[2][r][ch] + red[3][r][ch];
+			double s = red[0][r][ch];
+#pragma unroll
+			for (int wv = 1; wv < kJWaves; ++wv) s += red[wv][r][ch];
 			const size_t gi = 3 * (size_t)(row0 + r0 + r) + ch;
 			const double rho = ch == 0 ? rho0 : (ch == 1 ? rho1 : rho2);
 			const double e = (double)E[gi];
@@ -350,7 +372,7 @@ int rtmi_jacobi_sweep_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t ro
 		return fail(std::string(who) + ": d_F / d_B_old must be 16-byte aligned and ld a multiple of 4");
 	if (d_B_old == d_B_new) return fail(std::string(who) + ": Jacobi needs distinct B_old and B_new");
 	const uint32_t grid = (n_rows + kRows - 1) / kRows;
-	hipLaunchKernelGGL(k_jacobi_sweep, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, d_F, ld, n, row0, n_rows, rho[0], rho[1],
+	hipLaunchKernelGGL(k_jacobi_sweep, dim3(grid), dim3(kJBlock), 0, (hipStream_t)stream, d_F, ld, n, row0, n_rows, rho[0], rho[1],
 	                   rho[2], d_E, d_B_old, d_B_new, d_norms);
 	return launch_check(who);
 }
