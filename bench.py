@@ -256,7 +256,8 @@ def main():
             ff_s = max_over_ranks(time.perf_counter() - t0)
             vis_rays = 10.0 * (rad.numOfElements - 1) * (nb - 1 if full else nr_s * world)
             formfactor = {"patches": rad.numOfElements, "rows_built_per_rank": nr_s, "seconds": round(ff_s, 4),
-                          "visibility_Mrays_per_s": round(vis_rays / ff_s / 1e6, 1), "samples_per_pair": 10,
+                          "pair_samples_M_per_s": round(vis_rays / ff_s / 1e6, 1), "samples_per_pair": 10,
+                          "note": "a visibility ray is shot only for samples whose two cosines are positive (others add 0 whatever the ray says)",
                           "full_matrix": full, "F_GiB_per_rank": round(nr_s * ldb * 4 / 2**30, 2)}
             if not full:
                 formfactor["extrapolated_full_build_seconds"] = round(ff_s * nr / nr_s, 1)

@@ -136,11 +136,13 @@ __device__ __forceinline__ uint32_t wave_slots() { // 64 on the first active lan
 	return (uint32_t)(__ffsll((long long)m) - 1) == (threadIdx.x & 63u) ? 64u : 0u;
 }
 
+struct HitP { double t; uint32_t pos; }; // pos: index into the leaf-ordered triangle array, RTMI_MISS = no hit (t = 0)
+
 template <bool ANY, bool COUNT = false>
 __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, double oz, double dx, double dy,
-                                      double dz, double tmax, int *stack, Hit &h, Work *w = nullptr) {
-	h.t = 0.0; h.u = 0.0; h.v = 0.0;
-	h.orig = RTMI_MISS; h.object = RTMI_MISS; h.pos = RTMI_MISS;
+                                      double dz, double tmax, int *stack, HitP &h, Work *w = nullptr) {
+	h.t = 0.0;
+	h.pos = RTMI_MISS;
 	double best = tmax;
 	float tbest = f32_above(best);
 	const RayF r = make_rayf(ox, oy, oz, dx, dy, dz, S.absmax);
@@ -191,14 +193,14 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 			bool done = false;
 			if (ANY) {
 				if (t > 0.0 && t < tmax) {
-					h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = tk;
+					h.t = t; h.pos = tk;
 					done = true;
 				}
 			} else {
-				if (t > 0.0 && (best > t || (t == best && h.orig != RTMI_MISS && T.orig < h.orig))) {
+				if (t > 0.0 && (best > t || (t == best && h.pos != RTMI_MISS && T.orig < S.tris[h.pos].orig))) {
 					best = t;
 					tbest = f32_above(best);
-					h.t = t; h.u = u; h.v = v; h.orig = T.orig; h.object = T.object; h.pos = tk;
+					h.t = t; h.pos = tk;
 				}
 			}
 			++tk;

@@ -50,20 +50,23 @@ __device__ __forceinline__ D3 sample_point(const double *__restrict__ e, uint64_
 }
 
 // Render2/radiosity.cpp:231-262 (+ :202-229, object.cpp:23): is xj on patch j visible from xi?
-__device__ __forceinline__ bool visible(const SceneDev &S, const PatchesDev &P, uint32_t j, D3 xi, D3 yi, int *stack) {
-	const D3 dir = unit(yi - xi);
-	const D3 org = xi + (kEpsilon * dir);
-	Hit h;
+// dir = Unit(xj − xi) and org = xi + 1e-5·dir are the caller's (the form-factor kernel reuses them).
+__device__ __forceinline__ bool visible_along(const SceneDev &S, const PatchesDev &P, uint32_t j, D3 org, D3 dir, D3 yi, int *stack) {
+	HitP h;
 	trace<false>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h);
-	if (h.orig == RTMI_MISS) return false;
+	if (h.pos == RTMI_MISS) return false;
 	// hit.point = o + (d·((v1 − o)·n)) / (n·d)   with the HIT triangle's first vertex and normal
 	const GTri &T = S.tris[h.pos];
-	const double *np = P.normals + 3 * (size_t)h.orig;
+	const double *np = P.normals + 3 * (size_t)T.orig;
 	const D3 n = d3(np[0], np[1], np[2]);
 	const D3 v1 = d3(T.v0[0], T.v0[1], T.v0[2]);
 	const D3 p = org + (dot(v1 - org, n) * dir) / dot(n, dir);
 	const double *nj = P.normals + 3 * (size_t)j;
 	return sqrt(len2(p - yi)) < kEpsilon && dot(dir, d3(nj[0], nj[1], nj[2])) < 0;
+}
+__device__ __forceinline__ bool visible(const SceneDev &S, const PatchesDev &P, uint32_t j, D3 xi, D3 yi, int *stack) {
+	const D3 dir = unit(yi - xi);
+	return visible_along(S, P, j, xi + (kEpsilon * dir), dir, yi, stack);
 }
 
 RTMI_TRAVERSAL_KERNEL void k_visible_points(SceneDev S, PatchesDev P, uint64_t m,
@@ -99,16 +102,23 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDe
 		const D3 ni = d3(P.normals[3 * (size_t)i], P.normals[3 * (size_t)i + 1], P.normals[3 * (size_t)i + 2]);
 		const D3 nj = d3(P.normals[3 * (size_t)j], P.normals[3 * (size_t)j + 1], P.normals[3 * (size_t)j + 2]);
 		const double area_j = P.area[j];
+		const double area_term = area_j / (int)samples; // :319, the same for every sample
 		double ff = 0.0;
 		for (uint32_t k = 0; k < samples; ++k) {
 			const D3 xi = sample_point(ei, seed, i, j, k, 0), xj = sample_point(ejp, seed, i, j, k, 1);
-			if (visible(S, P, j, xi, xj, stack)) {
-				const D3 ab = xi - xj;
-				const double dist2 = dot(ab, ab);
-				const double c1 = dot(unit(xj - xi), ni);
-				const double c2 = dot(unit(xi - xj), nj);
+			// Unit(xj − xi) once: the reference evaluates it three times (:235, :317, and Unit(xi − xj) = its exact
+			// negation, :318), and dist2 = (xi−xj)·(xi−xj) is the squared length inside it — same IEEE operations.
+			const D3 vec = xj - xi;
+			const double dist2 = len2(vec);
+			const D3 dir = dist2 > 0.0 ? vec / sqrt(dist2) : d3(0, 0, 0);
+			// A sample adds to the sum only if delF > 0, i.e. both cosines are positive (:320-324) — whatever the
+			// visibility ray says.  So the ray is shot only for those samples: back-facing and coplanar pairs
+			// (the grazing rays along a wall, the most expensive ones) cost nothing, and F is unchanged bit for bit.
+			const double c1 = dot(dir, ni);
+			const double c2 = -dot(dir, nj);
+			if (c1 > 0.0 && c2 > 0.0 && visible_along(S, P, j, xi + (kEpsilon * dir), dir, xj, stack)) {
 				const double cosFactor = c1 * c2;
-				const double delF = (c1 < 0.0 || c2 < 0.0) ? 0.0 : cosFactor / ((kPi * dist2) + (area_j / (int)samples));
+				const double delF = cosFactor / ((kPi * dist2) + area_term);
 				if (delF > 0.0) ff += delF;
 			}
 		}
@@ -125,12 +135,12 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDe
 			const D3 x = sample_point(ei, seed, i, kLightStream, k, 0);
 			const D3 dir = unit(C - x);
 			const D3 org = x + (kEpsilon * ni);
-			Hit h;
-			trace<true>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h);
-			if (h.orig == RTMI_MISS) {
-				const double L = sqrt(len2(C - x));
-				const double tmp = ((1.0 / (4.0 * kPi)) * (dot(dir, ni) / (L * L)));
-				if (tmp > 0.0) ff += tmp;
+			const double L = sqrt(len2(C - x));
+			const double tmp = ((1.0 / (4.0 * kPi)) * (dot(dir, ni) / (L * L)));
+			if (tmp > 0.0) { // only a positive term is ever added (:297-299): the ray is needed for those alone
+				HitP h;
+				trace<true>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h);
+				if (h.pos == RTMI_MISS) ff += tmp;
 			}
 		}
 		out = light_samples ? ff / ((double)light_samples) : 0.0;

@@ -19,6 +19,6 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 dig = hashlib.sha1(F.cpu().numpy().tobytes()).hexdigest()[:12]
 i = box.info()
-print("box %d patches depth %d | %d rows %.4f s  %.1f M visibility rays/s  full build %.1f s  row sum %.4f digest %s %s" % (
+print("box %d patches depth %d | %d rows %.4f s  %.1f M pair-samples/s  full build %.1f s  row sum %.4f digest %s %s" % (
     rad.numOfElements, i.max_depth, rows, dt, 10.0 * rows * (rad.n - 2) / dt / 1e6, dt * rad.n / rows, float(F[0].sum()), dig,
     os.environ.get("TAG", "")), flush=True)
