@@ -303,6 +303,57 @@ def main():
                    "" if args.cpu_row_stride == 1 else "%d-th" % args.cpu_row_stride, x_res, y_res, len(d), reps, secs),
                "gpu_vs_oracle_mismatches_on_sample": mism}
 
+    # ------------------------------------------------------------------ C1: the compiled reference itself (configs[0])
+    # The reference cannot run C3 (its BSP build is quadratic and throws on real meshes), so its own CPU path is
+    # timed on its own scene: test1, 500x400 primary rays through Scene::Cast, beside the GPU on the same frame.
+    # Needs oracle/_ref/libref_render2.so (built where /root/reference exists; the .so travels to the GPU box).
+    c1 = None
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref_render2.so")
+    if world == 1 and rank == 0 and not args.no_cpu and os.path.exists(ref_so):
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle_py import Reference
+        g = np.load(os.path.join(ROOT, "tests", "golden", "g2_test1.npz"))
+        ref = Reference(ref_so)
+        work = tempfile.mkdtemp()
+        h, ok = None, False
+        for _ in range(10):                       # the reference's BSP build uses an unseeded RNG and may throw
+            h = ref.scene_from_triangles(g["tris"], g["tri_obj"], g["light_center"])
+            if ref.build_bsp(h, work) == 0:
+                ok = True
+                break
+        if ok:
+            s1 = rt.Scene(g["tris"], g["tri_obj"])
+            cam1 = rt.Camera.from_cam14(g["cam"], g["res"])
+            n1 = cam1.x_res * cam1.y_res
+            r1 = torch.zeros(n1 * 64, dtype=torch.uint8, device="cuda")
+            o1 = torch.zeros(n1 * 24, dtype=torch.uint8, device="cuda")
+            rt.primary_rays_dev(cam1, r1.data_ptr(), stream=stream)
+            s1.primary_dev(cam1, o1.data_ptr(), tile=TILE, stream=stream)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                s1.primary_dev(cam1, o1.data_ptr(), tile=TILE, stream=stream)
+            e1.record()
+            torch.cuda.synchronize()
+            gpu_ms = e0.elapsed_time(e1) / 20
+            hr = r1.cpu().numpy().view(rt.RAY_DTYPE)
+            hh = o1.cpu().numpy().view(rt.HIT_DTYPE)
+            secs, reps, c = 0.0, 0, None
+            while secs < 10.0 and reps < 40:       # about 10 s of the reference's Scene::Cast, 1 thread as shipped
+                c = ref.cast(h, hr["o"], hr["d"])
+                secs += c["seconds"]
+                reps += 1
+            hit = hh["tri"] != rt.MISS
+            same = bool(np.array_equal(c["hit"].astype(bool), hit))
+            dmax = float(np.max(np.abs(c["dist"][hit] - hh["t"][hit]) / hh["t"][hit])) if hit.any() else 0.0
+            c1 = {"workload": "C1: Render2/scenes/test1 (24 triangles), 500x400 primary rays, closest hit",
+                  "reference_Mrays_per_s": round(reps * n1 / secs / 1e6, 4), "reference_cores": 1, "kind": "reference",
+                  "sample": "%d frames of Scene::Cast through the reference's BSP = %.1f s" % (reps, secs),
+                  "gpu_Mrays_per_s": round(n1 / gpu_ms / 1e3, 1), "gpu_ms": round(gpu_ms, 4),
+                  "same_hit_miss": same, "max_rel_distance_diff": dmax}
+
     if rank == 0:
         line = {
             "metric": "closest-hit Mrays/s on 1M-tri scene; form-factor+solve time @64K patches",
@@ -317,7 +368,7 @@ def main():
                                "max_leaf": int(info.max_leaf_size), "build_seconds": round(info.build_seconds, 2),
                                "device_MB": round(info.device_bytes / 1e6, 1)}},
             "roofline": roofline, "roofline_traversal": roofline_traversal, "solver": solver, "formfactor": formfactor,
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "c1_reference": c1,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

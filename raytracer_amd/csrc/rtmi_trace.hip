@@ -190,9 +190,9 @@ unsigned env_uint(const char *name, unsigned dflt) {
 
 Tune refill_threshold() {
 	Tune t;
-	t.thresh = (int)std::min(64u, env_uint("RTMI_REFILL", 16));
-	t.vote_node = (int)env_uint("RTMI_VOTE_NODE", 1);
-	t.vote_leaf = (int)env_uint("RTMI_VOTE_LEAF", 1);
+	t.thresh = (int)std::min(64u, env_uint("RTMI_REFILL", 32));
+	t.vote_node = (int)env_uint("RTMI_VOTE_NODE", 2);
+	t.vote_leaf = (int)env_uint("RTMI_VOTE_LEAF", 3);
 	return t;
 }
 
@@ -494,7 +494,7 @@ int rtmi_primary_closest_hit_dev(rtmi_scene *s, const rtmi_camera *cam, double s
 	PrimaryGrid g;
 	const int64_t grid = primary_grid(cam, tile_w, tile_h, tile_first, tile_stride, g, who);
 	if (grid <= 0) return (int)grid;
-	hipLaunchKernelGGL(k_primary_closest, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes + 16, (hipStream_t)stream, s->dev,
+	hipLaunchKernelGGL(k_primary_closest, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes + 16 + env_uint("RTMI_LDS_PAD", 0) /* diagnosis: caps the workgroups per CU */, (hipStream_t)stream, s->dev,
 	                   s->stack_bytes, *cam, sx, sy, g, refill_threshold(), d_out);
 	return launch_check(who);
 }
