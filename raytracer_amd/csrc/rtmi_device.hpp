@@ -11,14 +11,18 @@
 namespace rtmi {
 
 // ---------------------------------------------------------------- HBM layout
-// BVH2 inner node, 64 B = half a 128-B L2 line; both children's fp32 boxes + their references.
-//   a = (lo0.x, hi0.x, lo0.y, hi0.y)   b = (lo1.x, hi1.x, lo1.y, hi1.y)
-//   c = (lo0.z, hi0.z, lo1.z, hi1.z)   d = (ref0, ref1, -, -)
+// BVH2 inner node, 32 B = a quarter of a 128-B L2 line = TWO 16-byte loads per lane: both children's boxes as
+// 16-bit coordinates on a grid over the scene bounds (plane = qlo + q·qstep per axis; lo planes rounded down, hi
+// planes up, so a quantised box contains the fp32 box) + the two child references.  The traversal kernels are
+// bound by vector-memory instruction issue under divergent addresses (measured: every extra dependent load per
+// node step costs as much as a quarter of the whole step), so halving the loads per node matters more than the
+// ~24 extra VALU instructions of the dequantisation.
+//   a = (lo0.x|hi0.x<<16, lo0.y|hi0.y<<16, lo0.z|hi0.z<<16, lo1.x|hi1.x<<16)
+//   b = (lo1.y|hi1.y<<16, lo1.z|hi1.z<<16, ref0, ref1)
 // ref >= 0: index of an inner node;  ref < 0: leaf, ~ref = (first << 3) | (count - 1), count <= 8,
 // first = index into the leaf-ordered triangle array.
-struct __attribute__((aligned(16))) GNode {
-	float4 a, b, c;
-	int4 d;
+struct __attribute__((aligned(16))) QNode {
+	uint4 a, b;
 };
 
 // Triangle in leaf order, 80 B: v0 and the two edges the reference recomputes for every test
@@ -46,7 +50,8 @@ constexpr int kLeaf = INT32_MIN + 1;      // lane state: working through the tri
 constexpr uint32_t kMaxFirst = 1u << 27; // leaf refs ~((first << 3) | cnt-1) stay above kLeaf
 
 struct SceneDev {
-	const GNode *nodes;
+	const QNode *nodes;
+	float qlo[3], qstep[3]; // the quantisation grid: plane = qlo + q·qstep (q = 0..65535)
 	const GTri *tris;
 	int32_t root_ref; // kSentinel for an empty scene
 	float absmax;     // max |coordinate| of the scene bounds (for the per-ray box padding)
@@ -90,14 +95,13 @@ __device__ __forceinline__ double mt_exact(double ox, double oy, double oz, doub
 // distance by which a ray accepted by the double MT can miss the triangle's true bounds
 // (DESIGN.md §"Why the boxes are safe").  The pad is folded into two copies of the origin, so it
 // costs no instruction per box.
-// Arithmetic: t = plane·(1/d) + (−(o ± pad)·(1/d)) as ONE fused multiply-add per plane (12 v_fma_f32 per node
-// instead of 12 subtractions + 12 multiplications).  The pre-rounded product −(o ± pad)/d carries an error of
-// 2^-24·|o ± pad| in distance units, far below the pad.  (Two planes per v_pk_fma_f32 was measured 10-16 %
-// SLOWER than the scalar form on the C3 frame and is not used.)
+// Arithmetic: plane = qlo + q·qstep, t = (plane − (o ± pad))/d = q·(qstep/d) + (qlo − (o ± pad))/d: ONE fused
+// multiply-add per plane on the integer coordinate.  The pre-rounded constants carry errors of a few 2^-24·|coord|
+// in distance units, far below the pad.
 struct RayF {
-	float ix, iy, iz;    // 1/d, |d| clamped away from 0 (no inf, hence no NaN from 0·inf)
-	float plx, ply, plz; // −(o + pad)/d : addend of the lo planes
-	float phx, phy, phz; // −(o − pad)/d : addend of the hi planes
+	float ax, ay, az;    // qstep/d, |d| clamped away from 0 (no inf, hence no NaN from 0·inf)
+	float blx, bly, blz; // (qlo − (o + pad))/d : addend of the lo planes
+	float bhx, bhy, bhz; // (qlo − (o − pad))/d : addend of the hi planes
 };
 
 __device__ __forceinline__ float safe_rcp(float d) {
@@ -106,26 +110,50 @@ __device__ __forceinline__ float safe_rcp(float d) {
 	return 1.0f / d;
 }
 
-__device__ __forceinline__ RayF make_rayf(double ox, double oy, double oz, double dx, double dy, double dz,
-                                          float absmax) {
+__device__ __forceinline__ RayF make_rayf(const SceneDev &S, double ox, double oy, double oz, double dx, double dy, double dz) {
 	const float fx = (float)ox, fy = (float)oy, fz = (float)oz;
-	const float pad = 3.814697265625e-06f * (absmax + fmaxf(fabsf(fx), fmaxf(fabsf(fy), fabsf(fz)))) + 1e-30f;
+	const float pad = 3.814697265625e-06f * (S.absmax + fmaxf(fabsf(fx), fmaxf(fabsf(fy), fabsf(fz)))) + 1e-30f;
+	const float ix = safe_rcp((float)dx), iy = safe_rcp((float)dy), iz = safe_rcp((float)dz);
 	RayF r;
-	r.ix = safe_rcp((float)dx); r.iy = safe_rcp((float)dy); r.iz = safe_rcp((float)dz);
-	r.plx = -(fx + pad) * r.ix; r.ply = -(fy + pad) * r.iy; r.plz = -(fz + pad) * r.iz;
-	r.phx = -(fx - pad) * r.ix; r.phy = -(fy - pad) * r.iy; r.phz = -(fz - pad) * r.iz;
+	r.ax = S.qstep[0] * ix; r.ay = S.qstep[1] * iy; r.az = S.qstep[2] * iz;
+	r.blx = fmaf(S.qlo[0], ix, -(fx + pad) * ix); r.bly = fmaf(S.qlo[1], iy, -(fy + pad) * iy); r.blz = fmaf(S.qlo[2], iz, -(fz + pad) * iz);
+	r.bhx = fmaf(S.qlo[0], ix, -(fx - pad) * ix); r.bhy = fmaf(S.qlo[1], iy, -(fy - pad) * iy); r.bhz = fmaf(S.qlo[2], iz, -(fz - pad) * iz);
 	return r;
 }
 
-__device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz, const RayF &r,
-                                     float tbest, float &tnear) {
-	const float ax = fmaf(lox, r.ix, r.plx), bx = fmaf(hix, r.ix, r.phx);
-	const float ay = fmaf(loy, r.iy, r.ply), by = fmaf(hiy, r.iy, r.phy);
-	const float az = fmaf(loz, r.iz, r.plz), bz = fmaf(hiz, r.iz, r.phz);
+// one box: the three (lo | hi << 16) words of its planes
+__device__ __forceinline__ bool slab(uint32_t wx, uint32_t wy, uint32_t wz, const RayF &r, float tbest, float &tnear) {
+	const float ax = fmaf((float)(wx & 0xffffu), r.ax, r.blx), bx = fmaf((float)(wx >> 16), r.ax, r.bhx);
+	const float ay = fmaf((float)(wy & 0xffffu), r.ay, r.bly), by = fmaf((float)(wy >> 16), r.ay, r.bhy);
+	const float az = fmaf((float)(wz & 0xffffu), r.az, r.blz), bz = fmaf((float)(wz >> 16), r.az, r.bhz);
 	const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
 	const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tbest));
 	tnear = tn;
 	return tn <= tf;
+}
+
+// One node step of a lane: fetch the node (2 × 16 B), test both children, go to the nearer hit child and push the
+// other one, or pop.  Returns the lane's next reference (inner node, raw leaf reference, or kSentinel).
+__device__ __forceinline__ int node_step(const SceneDev &S, const RayF &r, float tbest, int cur, int &sp, int *stack) {
+	const QNode *np = S.nodes + cur;
+	const uint4 a = np->a, b = np->b;
+	float t0, t1;
+	const bool h0 = slab(a.x, a.y, a.z, r, tbest, t0);
+	const bool h1 = slab(a.w, b.x, b.y, r, tbest, t1);
+	const int r0 = (int)b.z, r1 = (int)b.w;
+	if (h0 && h1) {
+		const bool swap = t1 < t0;
+		stack[sp * kBlock] = swap ? r0 : r1;
+		++sp;
+		return swap ? r1 : r0;
+	}
+	if (h0) return r0;
+	if (h1) return r1;
+	if (sp > 0) {
+		--sp;
+		return stack[sp * kBlock];
+	}
+	return kSentinel;
 }
 
 // float >= x (x >= 0)
@@ -153,7 +181,7 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 	h.pos = RTMI_MISS;
 	double best = tmax;
 	float tbest = f32_above(best);
-	const RayF r = make_rayf(ox, oy, oz, dx, dy, dz, S.absmax);
+	const RayF r = make_rayf(S, ox, oy, oz, dx, dy, dz);
 	int sp = 0;
 	int cur = S.root_ref;
 	uint32_t tk = 0, tend = 0;
@@ -170,28 +198,8 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 		if (n_node + n_leaf == 0) break;
 		if (n_node >= n_leaf) {
 			if (cur >= 0) {
-				const GNode *np = S.nodes + cur;
 				if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
-				const float4 a = np->a, b = np->b, c = np->c;
-				const int4 d = np->d;
-				float t0, t1;
-				const bool h0 = slab(a.x, a.y, a.z, a.w, c.x, c.y, r, tbest, t0);
-				const bool h1 = slab(b.x, b.y, b.z, b.w, c.z, c.w, r, tbest, t1);
-				if (h0 && h1) {
-					const bool swap = t1 < t0;
-					cur = swap ? d.y : d.x;
-					stack[sp * kBlock] = swap ? d.x : d.y;
-					++sp;
-				} else if (h0) {
-					cur = d.x;
-				} else if (h1) {
-					cur = d.y;
-				} else if (sp > 0) {
-					--sp;
-					cur = stack[sp * kBlock];
-				} else {
-					cur = kSentinel;
-				}
+				cur = node_step(S, r, tbest, cur, sp, stack);
 			}
 		} else if (cur == kLeaf) {
 			if (COUNT) { ++w->tests; w->test_slots += wave_slots(); }
@@ -258,7 +266,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
                                             Emit emit, Work *w = nullptr) {
 	const uint32_t lane = threadIdx.x & 63u;
 	RayD R = {0, 0, 0, 0, 0, 1, 0};
-	RayF r = {1, 1, 1, 0, 0, 0, 0, 0, 0};
+	RayF r = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	HitQ h = {0.0, 0.f, 0.f, RTMI_MISS};
 	double best = 0.0;
 	float tbest = 0.f;
@@ -271,7 +279,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 		h.u = h.v = 0.f; h.pos = RTMI_MISS;
 		best = R.tmax;
 		tbest = f32_above(best);
-		r = make_rayf(UNIFORM_O ? uox : R.ox, UNIFORM_O ? uoy : R.oy, UNIFORM_O ? uoz : R.oz, R.dx, R.dy, R.dz, S.absmax);
+		r = make_rayf(S, UNIFORM_O ? uox : R.ox, UNIFORM_O ? uoy : R.oy, UNIFORM_O ? uoz : R.oz, R.dx, R.dy, R.dz);
 		sp = 0;
 		cur = S.root_ref;
 	};
@@ -329,28 +337,8 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 #pragma unroll
 			for (int rep = 0; rep < kNodeSteps; ++rep)
 			if (cur >= 0) {
-				const GNode *np = S.nodes + cur;
 				if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
-				const float4 a = np->a, b = np->b, c = np->c;
-				const int4 d = np->d;
-				float t0, t1;
-				const bool h0 = slab(a.x, a.y, a.z, a.w, c.x, c.y, r, tbest, t0);
-				const bool h1 = slab(b.x, b.y, b.z, b.w, c.z, c.w, r, tbest, t1);
-				if (h0 && h1) {
-					const bool swap = t1 < t0;
-					cur = swap ? d.y : d.x;
-					stack[sp * kBlock] = swap ? d.x : d.y;
-					++sp;
-				} else if (h0) {
-					cur = d.x;
-				} else if (h1) {
-					cur = d.y;
-				} else if (sp > 0) {
-					--sp;
-					cur = stack[sp * kBlock];
-				} else {
-					cur = kSentinel;
-				}
+				cur = node_step(S, r, tbest, cur, sp, stack);
 			}
 		} else {
 			if (cur == kLeaf) {

@@ -217,6 +217,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	std::memcpy(s->info.scene_hi, bvh.hi, sizeof bvh.hi);
 	if (hipGetDevice(&s->device) != hipSuccess) { delete s; fail("hipGetDevice failed"); return nullptr; }
 	s->dev.nodes = nullptr; s->dev.tris = nullptr; s->dev.root_ref = kSentinel; s->dev.absmax = 0.f;
+	for (int a = 0; a < 3; ++a) { s->dev.qlo[a] = 0.f; s->dev.qstep[a] = 0.f; }
 	s->d_v1_orig = nullptr;
 	// one push per inner node on a root-to-leaf path at most: depth entries, +1 spare
 	s->stack_bytes = (bvh.depth + 1u) * kBlock * (uint32_t)sizeof(int);
@@ -238,7 +239,33 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	}
 	// inner nodes in depth-first order (a node's near subtree follows it in memory)
 	auto ref_of_leaf = [](const BuildNode &b) { return (int32_t) ~((b.first << 3) | (b.count - 1)); };
-	std::vector<GNode> nodes;
+	// the 16-bit grid over the scene bounds: plane = qlo + q·qstep, evaluated by the kernels in fp32.  qstep is
+	// rounded up until qlo + 65535·qstep covers the scene; lo planes are rounded down and hi planes up against
+	// the very values the kernels use, so a quantised box always contains the fp32 box.
+	float qlo[3], qstep[3];
+	for (int a = 0; a < 3; ++a) {
+		qlo[a] = bvh.lo[a];
+		const double ext = (double)bvh.hi[a] - (double)bvh.lo[a];
+		float st = (float)(ext / 65535.0);
+		while (ext > 0.0 && (double)qlo[a] + 65535.0 * (double)st < (double)bvh.hi[a]) st = std::nextafterf(st, INFINITY);
+		qstep[a] = st;
+	}
+	auto q_lo = [&](float v, int a) -> uint32_t {
+		if (!(qstep[a] > 0.f)) return 0u;
+		double q = std::floor(((double)v - (double)qlo[a]) / (double)qstep[a]);
+		q = std::min(65535.0, std::max(0.0, q));
+		while (q > 0.0 && (double)qlo[a] + q * (double)qstep[a] > (double)v) q -= 1.0;
+		return (uint32_t)q;
+	};
+	auto q_hi = [&](float v, int a) -> uint32_t {
+		if (!(qstep[a] > 0.f)) return 0u;
+		double q = std::ceil(((double)v - (double)qlo[a]) / (double)qstep[a]);
+		q = std::min(65535.0, std::max(0.0, q));
+		while (q < 65535.0 && (double)qlo[a] + q * (double)qstep[a] < (double)v) q += 1.0;
+		return (uint32_t)q;
+	};
+	auto plane_word = [&](const BuildNode &c, int a) { return q_lo(c.lo[a], a) | (q_hi(c.hi[a], a) << 16); };
+	std::vector<QNode> nodes;
 	const BuildNode &root = bvh.nodes[0];
 	int32_t root_ref;
 	if (root.left < 0) {
@@ -260,11 +287,9 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 			else { r1 = (int32_t)nodes.size(); nodes.emplace_back(); todo.push_back({(uint32_t)b.right, r1}); }
 			if (c0.left < 0) r0 = ref_of_leaf(c0);
 			else { r0 = (int32_t)nodes.size(); nodes.emplace_back(); todo.push_back({(uint32_t)b.left, r0}); }
-			GNode g;
-			g.a = make_float4(c0.lo[0], c0.hi[0], c0.lo[1], c0.hi[1]);
-			g.b = make_float4(c1.lo[0], c1.hi[0], c1.lo[1], c1.hi[1]);
-			g.c = make_float4(c0.lo[2], c0.hi[2], c1.lo[2], c1.hi[2]);
-			g.d = make_int4(r0, r1, 0, 0);
+			QNode g;
+			g.a = make_uint4(plane_word(c0, 0), plane_word(c0, 1), plane_word(c0, 2), plane_word(c1, 0));
+			g.b = make_uint4(plane_word(c1, 1), plane_word(c1, 2), (uint32_t)r0, (uint32_t)r1);
 			nodes[it.out_id] = g;
 		}
 		root_ref = 0;
@@ -275,9 +300,9 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	std::vector<double> v1(3 * n);
 	for (uint64_t k = 0; k < n; ++k)
 		for (int a = 0; a < 3; ++a) v1[3 * k + a] = xyz[9 * k + a];
-	GNode *d_nodes = nullptr;
+	QNode *d_nodes = nullptr;
 	GTri *d_tris = nullptr;
-	const size_t nb = std::max<size_t>(1, nodes.size()) * sizeof(GNode), tb = tris.size() * sizeof(GTri);
+	const size_t nb = std::max<size_t>(1, nodes.size()) * sizeof(QNode), tb = tris.size() * sizeof(GTri);
 	if (hipMalloc(&d_nodes, nb) != hipSuccess || hipMalloc(&d_tris, tb) != hipSuccess ||
 	    hipMalloc(&s->d_v1_orig, v1.size() * sizeof(double)) != hipSuccess) {
 		if (d_nodes) (void)hipFree(d_nodes);
@@ -288,7 +313,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		return nullptr;
 	}
 	bool ok = true;
-	if (!nodes.empty()) ok = ok && hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(GNode), hipMemcpyHostToDevice) == hipSuccess;
+	if (!nodes.empty()) ok = ok && hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(QNode), hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(d_tris, tris.data(), tb, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(s->d_v1_orig, v1.data(), v1.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
 	if (!ok) {
@@ -298,6 +323,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		return nullptr;
 	}
 	s->dev.nodes = d_nodes; s->dev.tris = d_tris; s->dev.root_ref = root_ref; s->dev.absmax = absmax;
+	for (int a = 0; a < 3; ++a) { s->dev.qlo[a] = qlo[a]; s->dev.qstep[a] = qstep[a]; }
 	s->info.n_nodes = nodes.size();
 	s->info.device_bytes = nb + tb + v1.size() * sizeof(double);
 	s->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
