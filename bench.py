@@ -30,9 +30,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 # algorithmic work per traversal event: one node visit = two fp32 slab tests,
 # one triangle test = the reference's Möller–Trumbore in fp64 (priced at 2 fp32-equivalents per flop)
-FLOP_NODE_VISIT = 46.0
+FLOP_NODE_VISIT = 46.0          # 2 boxes x (6 fma = 12 flop + 11 min/max)
 FLOP_TRI_TEST = 46.0 * 2.0
-BYTES_NODE, BYTES_TRI, BYTES_HIT = 64.0, 80.0, 24.0
+BYTES_NODE, BYTES_TRI, BYTES_HIT = 32.0, 80.0, 24.0
 
 
 def halton(i, b):
