@@ -57,11 +57,6 @@ struct SceneDev {
 	float absmax;     // max |coordinate| of the scene bounds (for the per-ray box padding)
 };
 
-struct Hit {
-	double t, u, v;
-	uint32_t orig, object, pos; // orig == RTMI_MISS: no hit.  pos = index into the leaf-ordered array
-};
-
 // ---------------------------------------------------------------- exact triangle test
 // Render2/object.cpp:29-60 in double, same operation order; inclusive edges; 0.0 = miss.
 // u, v are only defined up to the point the reference assigns them.
