@@ -131,10 +131,10 @@ def main():
     mrays = rays_total * args.steps / dt / 1e6
 
     # traversal work of the frame (diagnostic kernel, untimed) -> roofline of the closest-hit kernel
-    counts = torch.zeros(4, dtype=torch.int64, device="cuda")
+    counts = torch.zeros(6, dtype=torch.int64, device="cuda")
     scene.primary_work_dev(cam, counts.data_ptr(), stream=stream)
     torch.cuda.synchronize()
-    visits, tests, vslots, tslots = (int(v) for v in counts.cpu())
+    visits, tests, vslots, tslots, wleaf, widle = (int(v) for v in counts.cpu())
     flop_per_ray = (visits * FLOP_NODE_VISIT + tests * FLOP_TRI_TEST) / n_pix
     l2_bytes_per_ray = (visits * BYTES_NODE + tests * BYTES_TRI) / n_pix + BYTES_HIT
     rays_per_launch = rays_rank / spp
@@ -146,6 +146,7 @@ def main():
         "node_visits_per_ray": round(visits / n_pix, 2), "tri_tests_per_ray": round(tests / n_pix, 2),
         "cache_bytes_per_ray": round(l2_bytes_per_ray, 1),
         "lane_occupancy_node_loop": round(visits / max(1, vslots), 3), "lane_occupancy_tri_loop": round(tests / max(1, tslots), 3),
+        "node_step_lanes_holding_a_leaf": round(wleaf / max(1, vslots), 3), "node_step_lanes_without_a_ray": round(widle / max(1, vslots), 3),
         "cache_gbs": round(l2_bytes_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e9, 1), "traffic": None,
     }
 

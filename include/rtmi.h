@@ -112,7 +112,8 @@ int rtmi_primary_rays_dev(const rtmi_camera *cam, double sx, double sy, rtmi_ray
 /* Diagnostic (no counterpart in the reference): the traversal work of the same frame of primary rays,
  * ADDED to d_counts[0] (node visits, two child boxes each), d_counts[1] (exact triangle tests) and
  * d_counts[2], d_counts[3] (lane slots the waves spent in the node loop / the triangle loop: 64 per
- * wave-iteration, so counts[0]/counts[2] is the lane occupancy of the node loop).  d_counts: 4 × uint64.
+ * wave-iteration, so counts[0]/counts[2] is the lane occupancy of the node loop), d_counts[4], d_counts[5]
+ * (lane-steps a lane sat out a node step because it held a leaf / had no ray).  d_counts: 6 × uint64.
  * bench.py prices the traversal kernel's roofline with it. */
 int rtmi_primary_work_dev(rtmi_scene *, const rtmi_camera *cam, double sx, double sy, uint64_t *d_counts, void *stream);
 

@@ -40,6 +40,7 @@ constexpr uint32_t kGuard = 1u << 26;      // wave-iterations after which trace_
 #define RTMI_NODE_STEPS 3
 #endif
 constexpr int kNodeSteps = RTMI_NODE_STEPS;  // node steps a wave takes per scheduling round of trace_queue
+constexpr uint32_t kQueueChunk = 256;     // items a wave takes from the launch's queue at a time (4 squares of 8x8 pixels)
 constexpr int kLeaf = INT32_MIN + 1;      // lane state: working through the triangles of a leaf
 // Traversal kernels are latency-bound: ask the register allocator for at least this many waves per SIMD.
 #ifndef RTMI_WAVES
@@ -161,7 +162,7 @@ __device__ __forceinline__ float f32_above(double x) { return __double2float_ru(
 //              original id (the in-order scan of Render2/object.cpp:143-168 keeps the first).
 // ANY = true : stop at the first triangle with 0 < t < tmax (Render2/shader.cpp:131,226).
 // COUNT = true additionally tallies node visits and triangle tests (the roofline's work count).
-struct Work { uint32_t nodes, tests, node_slots, test_slots; }; // *_slots: 64 per wave-iteration (lane occupancy = nodes / node_slots)
+struct Work { uint32_t nodes, tests, node_slots, test_slots, wait_leaf, wait_idle; }; // *_slots: 64 per wave-iteration (lane occupancy = nodes / node_slots)
 __device__ __forceinline__ uint32_t wave_slots() { // 64 on the first active lane of the wave, 0 elsewhere
 	const unsigned long long m = __ballot(1);
 	return (uint32_t)(__ffsll((long long)m) - 1) == (threadIdx.x & 63u) ? 64u : 0u;
@@ -229,20 +230,12 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 // refill threshold and phase-vote weights of trace_queue (RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF override)
 struct Tune { int thresh, vote_node, vote_leaf; };
 
-// Dynamic LDS of every traversal kernel: the lanes' stacks (rtmi_scene::stack_bytes) followed by the
-// workgroup's queue counter.
-__device__ __forceinline__ int *queue_counter(int *stack, uint32_t stack_bytes) {
-	int *c = stack + stack_bytes / sizeof(int);
-	if (threadIdx.x == 0) *c = 0;
-	__syncthreads();
-	return c;
-}
-
-
-// A workgroup owns `n_items` work items (rays) and an LDS counter.  Every lane traces one ray at a time;
-// whenever at least `thresh` lanes of a wave are idle, the wave claims that many items with ONE LDS atomic
-// (ballot + mbcnt give each idle lane its slot) and the idle lanes start new rays while the others carry
-// on.  Ray lengths in a scene are close to exponentially distributed, so without this a wave runs for
+// The launch owns `n_items` work items (rays) and ONE counter in device memory (zeroed on the stream before the
+// kernel); its grid is persistent — as many workgroups as the device holds at once.  Every lane traces one ray at
+// a time; whenever at least `thresh` lanes of a wave are idle, the wave claims that many items with ONE atomic
+// (ballot + mbcnt give each idle lane its slot) and the idle lanes start new rays while the others carry on.
+// (A counter per workgroup in LDS over 2048 items was the first form: its waves idled at the end of every
+// workgroup's queue — 30 % of the lanes of a node step had no ray.)  Ray lengths in a scene are close to exponentially distributed, so without this a wave runs for
 // the longest of its 64 rays (measured 20 % lane occupancy in the node loop on the 1 Mi-triangle soup).
 //   fetch(item, R) -> bool    fill the first ray of a work item (false: no ray for this item)
 //   emit(item, h, R) -> bool  consume the hit record; true = R now holds the item's NEXT ray (form factors:
@@ -268,7 +261,9 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 	int sp = 0, cur = kSentinel;
 	uint32_t item = 0, tk = 0, tend = 0; // [tk, tend): triangles of the leaf this lane is working through (cur == kLeaf)
 	bool have = false; // this lane holds a ray (in flight, or finished and not yet emitted)
-	bool more = true;  // the queue still has items (wave-uniform)
+	bool more = true;  // items are left for this wave: in its own range or in the launch's queue (wave-uniform)
+	bool global_more = true;
+	uint32_t w_next = 0, w_end = 0; // the wave's own range of claimed items (wave-uniform)
 	uint32_t guard = 0;
 	auto start = [&]() { // R holds a new ray: reset the lane's traversal state
 		h.u = h.v = 0.f; h.pos = RTMI_MISS;
@@ -293,22 +288,47 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 			}
 			if (more) {
 				const unsigned long long idle = __ballot(!have);
-				const int nidle = __popcll(idle);
+				const uint32_t nidle = (uint32_t)__popcll(idle);
 				if (nidle > 0) {
-					uint32_t base = 0;
-					const uint32_t leader = (uint32_t)(__ffsll((long long)idle) - 1);
-					if (lane == leader) base = (uint32_t)atomicAdd(counter, nidle);
-					base = __shfl(base, (int)leader, 64);
+					// Items come from the wave's own range [w_next, w_end); when that runs short the wave takes the
+					// next kQueueChunk items from the launch's counter (one atomic per chunk, not per refill: thousands
+					// of waves adding to one address was measured to serialise).
+					const uint32_t left = w_end - w_next;
+					uint32_t fresh = 0, fresh_end = 0;
+					bool got = false;
+					if (left < nidle && global_more) {
+						const uint32_t leader = (uint32_t)(__ffsll((long long)idle) - 1);
+						uint32_t base = 0;
+						if (lane == leader) base = (uint32_t)atomicAdd(counter, (int)kQueueChunk);
+						fresh = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+						if (fresh >= n_items) {
+							global_more = false;
+						} else {
+							got = true;
+							fresh_end = fresh + kQueueChunk < n_items ? fresh + kQueueChunk : n_items;
+						}
+					}
 					if (!have) {
 						const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-						const uint32_t idx = base + below;
-						if (idx < n_items && fetch(idx, R)) {
+						uint32_t idx = 0;
+						bool ok = false;
+						if (below < left) { idx = w_next + below; ok = true; }
+						else if (got) { idx = fresh + (below - left); ok = idx < fresh_end; }
+						if (ok && fetch(idx, R)) {
 							item = idx;
 							have = true;
 							start();
 						}
 					}
-					if (base + (uint32_t)nidle >= n_items) more = false;
+					if (left >= nidle) {
+						w_next += nidle;
+					} else if (got) {
+						w_next = fresh + (nidle - left) < fresh_end ? fresh + (nidle - left) : fresh_end;
+						w_end = fresh_end;
+					} else {
+						w_next = w_end;
+					}
+					more = global_more || w_next < w_end;
 				}
 			}
 		}
@@ -330,10 +350,15 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 		if (n_node * vote_node >= n_leaf * vote_leaf) {
 			// kNodeSteps node steps per round: the retire/refill test and the vote are paid once for them
 #pragma unroll
-			for (int rep = 0; rep < kNodeSteps; ++rep)
-			if (cur >= 0) {
-				if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
-				cur = node_step(S, r, tbest, cur, sp, stack);
+			for (int rep = 0; rep < kNodeSteps; ++rep) {
+				if (COUNT && __ballot(cur >= 0) != 0ull) { // who sits out this node step, and why
+					if (cur < 0 && cur != kSentinel) ++w->wait_leaf;     // holds a leaf, waits for a triangle round
+					else if (cur == kSentinel) ++w->wait_idle;            // finished or without a ray, waits for the refill
+				}
+				if (cur >= 0) {
+					if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
+					cur = node_step(S, r, tbest, cur, sp, stack);
+				}
 			}
 		} else {
 			if (cur == kLeaf) {

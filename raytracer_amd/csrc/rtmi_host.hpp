@@ -1,5 +1,6 @@
 // Host-side declarations shared by the translation units of librtmi.
 #pragma once
+#include <atomic>
 #include <string>
 
 #include "bvh_build.hpp"
@@ -11,10 +12,14 @@ struct rtmi_scene {
 	int device;
 	uint32_t stack_bytes; // dynamic LDS of every traversal kernel: (BVH depth + 1) ints per lane
 	rtmi_scene_info info;
+	int *d_queue;                     // ring of work-queue counters, one per launch in flight (kQueueSlots)
+	std::atomic<uint32_t> next_slot;
+	int n_cus;
 	double *d_v1_orig; // n_tris × 3: triVert1 of every triangle in ORIGINAL order (hit points, object.cpp:23)
 };
 
 namespace rtmi {
+constexpr uint32_t kQueueSlots = 256;
 extern thread_local std::string g_err;
 int fail(const std::string &msg);        // records msg for rtmi_last_error(), returns -1
 int launch_check(const char *who);

@@ -30,16 +30,15 @@ __device__ __forceinline__ rtmi_hit hit_record(const SceneDev &S, const HitQ &h)
 	return o;
 }
 
-// Rays from a buffer: workgroup b owns rays [b·chunk, (b+1)·chunk) and works through them as a queue
+// Rays from a buffer: the launch's waves work through rays [0, n) as ONE queue (a counter in device memory)
 // (trace_queue); callers that care about coherence sort the buffer first.
 template <bool ANY>
-RTMI_TRAVERSAL_KERNEL void k_trace_rays(SceneDev S, uint32_t stack_bytes, const rtmi_ray *__restrict__ rays,
-                                                       uint64_t n, uint32_t chunk, Tune tune, rtmi_hit *__restrict__ out,
+RTMI_TRAVERSAL_KERNEL void k_trace_rays(SceneDev S, const rtmi_ray *__restrict__ rays,
+                                                       uint64_t n, int *__restrict__ counter, Tune tune, rtmi_hit *__restrict__ out,
                                                        uint8_t *__restrict__ occluded) {
 	extern __shared__ int stack[];
-	int *counter = queue_counter(stack, stack_bytes);
-	const uint64_t base = (uint64_t)blockIdx.x * chunk;
-	const uint32_t items = (uint32_t)(n - base < (uint64_t)chunk ? n - base : (uint64_t)chunk);
+	const uint64_t base = 0;
+	const uint32_t items = (uint32_t)n;
 	auto fetch = [&](uint32_t idx, RayD &R) {
 		const rtmi_ray q = rays[base + idx];
 		if (q.reserved != 0.0) { // an inactive slot of a wavefront (e.g. the shadow ray of a pixel that hit nothing)
@@ -90,14 +89,14 @@ __device__ __forceinline__ bool primary_pixel(const PrimaryGrid &g, const rtmi_c
 }
 
 // Primary rays generated in registers, 0 input bytes per ray.
-RTMI_TRAVERSAL_KERNEL void k_primary_closest(SceneDev S, uint32_t stack_bytes, rtmi_camera cam, double sx,
-                                                            double sy, PrimaryGrid g, Tune tune,
+RTMI_TRAVERSAL_KERNEL void k_primary_closest(SceneDev S, int *__restrict__ counter, uint32_t n_items, rtmi_camera cam,
+                                                            double sx, double sy, PrimaryGrid g, Tune tune,
                                                             rtmi_hit *__restrict__ out) {
 	extern __shared__ int stack[];
-	int *counter = queue_counter(stack, stack_bytes);
+	const uint32_t per_block = g.blk_w * g.blk_h; // item -> (pixel block, pixel within the block)
 	auto fetch = [&](uint32_t idx, RayD &R) {
 		uint32_t i, j;
-		if (!primary_pixel(g, cam, blockIdx.x, idx, i, j)) return false;
+		if (!primary_pixel(g, cam, idx / per_block, idx % per_block, i, j)) return false;
 		const D3 d = primary_dir(cam, i, j, sx, sy);
 		R.dx = d.x; R.dy = d.y; R.dz = d.z;
 		R.tmax = RTMI_INFINITY;
@@ -105,46 +104,38 @@ RTMI_TRAVERSAL_KERNEL void k_primary_closest(SceneDev S, uint32_t stack_bytes, r
 	};
 	auto emit = [&](uint32_t idx, const HitQ &h, RayD &) {
 		uint32_t i, j;
-		primary_pixel(g, cam, blockIdx.x, idx, i, j);
+		primary_pixel(g, cam, idx / per_block, idx % per_block, i, j);
 		out[(uint64_t)i * cam.x_res + j] = hit_record(S, h);
 		return false;
 	};
-	trace_queue<false, false, true>(S, stack + threadIdx.x, counter, g.blk_w * g.blk_h, tune.thresh, tune.vote_node, tune.vote_leaf, cam.eye[0], cam.eye[1], cam.eye[2],
+	trace_queue<false, false, true>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, cam.eye[0], cam.eye[1], cam.eye[2],
 	                                fetch, emit);
 }
 
 // Same rays as k_primary_closest (all tiles); only counts the traversal work: counts[0] += node visits
 // (one visit = two child boxes), counts[1] += exact triangle tests, counts[2..3] += the lane slots the wave spent on
 // them (64 per wave-iteration: visits / slots = lane occupancy of that loop).  Diagnostic, not on the hot path.
-RTMI_TRAVERSAL_KERNEL void k_primary_work(SceneDev S, uint32_t stack_bytes, rtmi_camera cam, double sx, double sy,
-                                                         PrimaryGrid g, Tune tune, unsigned long long *__restrict__ counts) {
+RTMI_TRAVERSAL_KERNEL void k_primary_work(SceneDev S, int *__restrict__ counter, uint32_t n_items, rtmi_camera cam, double sx,
+                                                         double sy, PrimaryGrid g, Tune tune, unsigned long long *__restrict__ counts) {
 	extern __shared__ int stack[];
-	int *counter = queue_counter(stack, stack_bytes);
+	const uint32_t per_block = g.blk_w * g.blk_h;
 	const uint32_t lane = threadIdx.x & 63u;
-	Work w = {0u, 0u, 0u, 0u};
+	Work w = {0u, 0u, 0u, 0u, 0u, 0u};
 	auto fetch = [&](uint32_t idx, RayD &R) {
 		uint32_t i, j;
-		if (!primary_pixel(g, cam, blockIdx.x, idx, i, j)) return false;
+		if (!primary_pixel(g, cam, idx / per_block, idx % per_block, i, j)) return false;
 		const D3 d = primary_dir(cam, i, j, sx, sy);
 		R.dx = d.x; R.dy = d.y; R.dz = d.z;
 		R.tmax = RTMI_INFINITY;
 		return true;
 	};
 	auto emit = [&](uint32_t, const HitQ &, RayD &) { return false; };
-	trace_queue<false, true, true>(S, stack + threadIdx.x, counter, g.blk_w * g.blk_h, tune.thresh, tune.vote_node, tune.vote_leaf, cam.eye[0], cam.eye[1], cam.eye[2],
+	trace_queue<false, true, true>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, cam.eye[0], cam.eye[1], cam.eye[2],
 	                               fetch, emit, &w);
-	unsigned long long a = w.nodes, b = w.tests, c = w.node_slots, e = w.test_slots;
-	for (int off = 32; off > 0; off >>= 1) {
-		a += __shfl_xor(a, off, 64);
-		b += __shfl_xor(b, off, 64);
-		c += __shfl_xor(c, off, 64);
-		e += __shfl_xor(e, off, 64);
-	}
-	if (lane == 0) {
-		atomicAdd(&counts[0], a);
-		atomicAdd(&counts[1], b);
-		atomicAdd(&counts[2], c);
-		atomicAdd(&counts[3], e);
+	unsigned long long v[6] = {w.nodes, w.tests, w.node_slots, w.test_slots, w.wait_leaf, w.wait_idle};
+	for (int k = 0; k < 6; ++k) {
+		for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+		if (lane == 0) atomicAdd(&counts[k], v[k]);
 	}
 }
 
@@ -190,9 +181,9 @@ unsigned env_uint(const char *name, unsigned dflt) {
 
 Tune refill_threshold() {
 	Tune t;
-	t.thresh = (int)std::min(64u, env_uint("RTMI_REFILL", 32));
-	t.vote_node = (int)env_uint("RTMI_VOTE_NODE", 2);
-	t.vote_leaf = (int)env_uint("RTMI_VOTE_LEAF", 3);
+	t.thresh = (int)std::min(64u, env_uint("RTMI_REFILL", 16));
+	t.vote_node = (int)env_uint("RTMI_VOTE_NODE", 1);
+	t.vote_leaf = (int)env_uint("RTMI_VOTE_LEAF", 2);
 	return t;
 }
 
@@ -219,6 +210,13 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	s->dev.nodes = nullptr; s->dev.tris = nullptr; s->dev.root_ref = kSentinel; s->dev.absmax = 0.f;
 	for (int a = 0; a < 3; ++a) { s->dev.qlo[a] = 0.f; s->dev.qstep[a] = 0.f; }
 	s->d_v1_orig = nullptr;
+	s->d_queue = nullptr;
+	s->next_slot = 0;
+	{
+		hipDeviceProp_t prop;
+		s->n_cus = (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+	}
+	if (hipMalloc(&s->d_queue, kQueueSlots * sizeof(int)) != hipSuccess) { delete s; fail("rtmi_scene_create: hipMalloc failed"); return nullptr; }
 	// one push per inner node on a root-to-leaf path at most: depth entries, +1 spare
 	s->stack_bytes = (bvh.depth + 1u) * kBlock * (uint32_t)sizeof(int);
 	if (n == 0) return s;
@@ -308,6 +306,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		if (d_nodes) (void)hipFree(d_nodes);
 		if (d_tris) (void)hipFree(d_tris);
 		if (s->d_v1_orig) (void)hipFree(s->d_v1_orig);
+		(void)hipFree(s->d_queue);
 		delete s;
 		fail("rtmi_scene_create: hipMalloc failed");
 		return nullptr;
@@ -317,7 +316,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	ok = ok && hipMemcpy(d_tris, tris.data(), tb, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(s->d_v1_orig, v1.data(), v1.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
 	if (!ok) {
-		(void)hipFree(d_nodes); (void)hipFree(d_tris); (void)hipFree(s->d_v1_orig);
+		(void)hipFree(d_nodes); (void)hipFree(d_tris); (void)hipFree(s->d_v1_orig); (void)hipFree(s->d_queue);
 		delete s;
 		fail("rtmi_scene_create: upload failed");
 		return nullptr;
@@ -344,18 +343,36 @@ int launch_check(const char *who) {
 	return 0;
 }
 
+// One queue counter per launch, taken round-robin from the scene's ring and zeroed on the launch's stream just before
+// the kernel: launches of one scene may overlap on different streams as long as fewer than kQueueSlots are in flight.
+static int *queue_slot(rtmi_scene *s, hipStream_t st, const char *who) {
+	int *slot = s->d_queue + (s->next_slot.fetch_add(1u) % kQueueSlots);
+	if (hipMemsetAsync(slot, 0, sizeof(int), st) != hipSuccess) { fail(std::string(who) + ": hipMemsetAsync failed"); return nullptr; }
+	return slot;
+}
+
+// Persistent grid: as many workgroups as the device holds at once (waves stay until the queue is empty), fewer for
+// launches too small to fill them.
+template <class K>
+static uint32_t persistent_grid(rtmi_scene *s, K kernel, uint64_t n_items) {
+	int per_cu = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, s->stack_bytes) != hipSuccess || per_cu < 1) per_cu = 4;
+	const uint64_t full = (uint64_t)per_cu * (uint64_t)s->n_cus;
+	return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full, (n_items + kBlock - 1) / kBlock));
+}
+
 template <bool ANY>
 static int trace_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, rtmi_hit *d_out, uint8_t *d_occ, void *stream,
                      const char *who) {
 	if (check_scene(s, who)) return -1;
 	if (n == 0) return 0;
 	if (!d_rays || (ANY ? !d_occ : !d_out)) return fail(std::string(who) + ": NULL buffer");
-	const uint32_t chunk = env_uint("RTMI_CHUNK", 2048);
-	const Tune thresh = refill_threshold();
-	const uint64_t grid = (n + chunk - 1) / chunk;
-	if (grid > 0x7fffffffull) return fail(std::string(who) + ": too many rays for one launch");
-	hipLaunchKernelGGL(k_trace_rays<ANY>, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes + 16, (hipStream_t)stream, s->dev,
-	                   s->stack_bytes, d_rays, n, chunk, thresh, d_out, d_occ);
+	if (n > 0xff000000ull) return fail(std::string(who) + ": too many rays for one launch");
+	int *slot = queue_slot(s, (hipStream_t)stream, who);
+	if (!slot) return -1;
+	const uint32_t grid = persistent_grid(s, k_trace_rays<ANY>, n);
+	hipLaunchKernelGGL(k_trace_rays<ANY>, dim3(grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, d_rays, n, slot,
+	                   refill_threshold(), d_out, d_occ);
 	return launch_check(who);
 }
 
@@ -403,6 +420,7 @@ void rtmi_scene_destroy(rtmi_scene *s) {
 	if (s->dev.nodes) (void)hipFree((void *)s->dev.nodes);
 	if (s->dev.tris) (void)hipFree((void *)s->dev.tris);
 	if (s->d_v1_orig) (void)hipFree(s->d_v1_orig);
+	if (s->d_queue) (void)hipFree(s->d_queue);
 	delete s;
 }
 
@@ -520,8 +538,12 @@ int rtmi_primary_closest_hit_dev(rtmi_scene *s, const rtmi_camera *cam, double s
 	PrimaryGrid g;
 	const int64_t grid = primary_grid(cam, tile_w, tile_h, tile_first, tile_stride, g, who);
 	if (grid <= 0) return (int)grid;
-	hipLaunchKernelGGL(k_primary_closest, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes + 16 + env_uint("RTMI_LDS_PAD", 0) /* diagnosis: caps the workgroups per CU */, (hipStream_t)stream, s->dev,
-	                   s->stack_bytes, *cam, sx, sy, g, refill_threshold(), d_out);
+	const uint64_t n_items = (uint64_t)grid * g.blk_w * g.blk_h;
+	if (n_items > 0xff000000ull) return fail(std::string(who) + ": too many pixels for one launch");
+	int *slot = queue_slot(s, (hipStream_t)stream, who);
+	if (!slot) return -1;
+	hipLaunchKernelGGL(k_primary_closest, dim3(persistent_grid(s, k_primary_closest, n_items)), dim3(kBlock), s->stack_bytes,
+	                   (hipStream_t)stream, s->dev, slot, (uint32_t)n_items, *cam, sx, sy, g, refill_threshold(), d_out);
 	return launch_check(who);
 }
 
@@ -532,8 +554,12 @@ int rtmi_primary_work_dev(rtmi_scene *s, const rtmi_camera *cam, double sx, doub
 	PrimaryGrid g;
 	const int64_t grid = primary_grid(cam, 64, 64, 0, 1, g, who);
 	if (grid <= 0) return (int)grid;
-	hipLaunchKernelGGL(k_primary_work, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes + 16, (hipStream_t)stream, s->dev,
-	                   s->stack_bytes, *cam, sx, sy, g, refill_threshold(), (unsigned long long *)d_counts);
+	const uint64_t n_items = (uint64_t)grid * g.blk_w * g.blk_h;
+	if (n_items > 0xff000000ull) return fail(std::string(who) + ": too many pixels for one launch");
+	int *slot = queue_slot(s, (hipStream_t)stream, who);
+	if (!slot) return -1;
+	hipLaunchKernelGGL(k_primary_work, dim3(persistent_grid(s, k_primary_work, n_items)), dim3(kBlock), s->stack_bytes, (hipStream_t)stream,
+	                   s->dev, slot, (uint32_t)n_items, *cam, sx, sy, g, refill_threshold(), (unsigned long long *)d_counts);
 	return launch_check(who);
 }
 

@@ -84,10 +84,10 @@ def test_c3_soup_frame_vs_oracle_sample_and_properties(rt, oracle, soup):
     b = frame(rt, scene, cam, tile=(128, 32), tile_first=1, tile_stride=2)
     assert torch.equal(torch.maximum(a, b), d_hits) and int((torch.minimum(a, b) != 0).sum()) == 0
     # (5) work counters are sane
-    counts = torch.zeros(4, dtype=torch.int64, device="cuda")
+    counts = torch.zeros(6, dtype=torch.int64, device="cuda")
     scene.primary_work_dev(cam, counts.data_ptr(), stream=st)
     torch.cuda.synchronize()
-    visits, tests, vslots, tslots = (int(x) for x in counts.cpu())
+    visits, tests, vslots, tslots, wleaf, widle = (int(x) for x in counts.cpu())
     assert n < visits < 400 * n and hit.sum() <= tests < 100 * n
 
 

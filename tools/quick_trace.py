@@ -26,11 +26,11 @@ ms = e0.elapsed_time(e1) / reps
 dig = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12]
 print("leaf<=%d depth %d nodes %d build %.2fs | %.3f ms  %.1f Mrays/s  digest %s %s" % (
     i.max_leaf_size, i.max_depth, i.n_nodes, i.build_seconds, ms, n / ms / 1e3, dig, os.environ.get("TAG", "")), flush=True)
-cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+cnt = torch.zeros(6, dtype=torch.int64, device="cuda")
 scene.primary_work_dev(cam, cnt.data_ptr(), stream=st); torch.cuda.synchronize()
-a, b, c, d = (int(x) for x in cnt.cpu())
-print("  per ray: %.1f visits %.1f tests; lane occupancy node loop %.3f tri loop %.3f; wave-iters/ray node %.2f tri %.2f" % (
-    a / n, b / n, a / max(c, 1), b / max(d, 1), c / 64 / n, d / 64 / n), flush=True)
+a, b, c, d, wl, wi = (int(x) for x in cnt.cpu())
+print("  per ray: %.1f visits %.1f tests; lane occupancy node loop %.3f tri loop %.3f; wave-iters/ray node %.2f tri %.2f; node-step lanes: %.3f busy, %.3f hold a leaf, %.3f without a ray" % (
+    a / n, b / n, a / max(c, 1), b / max(d, 1), c / 64 / n, d / 64 / n, a / max(c, 1), wl / max(c, 1), wi / max(c, 1)), flush=True)
 # incoherent rays: the same rays in a random order through the ray-buffer path
 rays = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
 rt.primary_rays_dev(cam, rays.data_ptr(), stream=st)
