@@ -141,6 +141,53 @@ int rtmi_ao_rays_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *d_ra
                      uint32_t spp, double radius, uint64_t seed, rtmi_ray *d_out, void *stream);
 int rtmi_occlusion_fraction_dev(const uint8_t *d_occluded, uint64_t n, uint32_t spp, double *d_out, void *stream);
 
+/* ---- frame: Scene::Trace + Shader::Shade as a wavefront -------------------------------------------------
+ * Replaces the recursion Scene::Trace (Render2/scene.cpp:127-155) -> Shader::Shade (Render2/shader.cpp:395-645, the
+ * branch the shipped main.cpp runs: scene.radiosity == NULL) -> Scene::Trace ..., and the pixel loop + ToneMap of
+ * Rasterizer::Serial_Normal_Raster (Render2/rasterizer.cpp:79-88, 219-233).  One generation of the ray tree is one
+ * batch: closest hit, shadow ray of generateNormalShadows (:105-138), ambient-occlusion rays of findOcclusionNew
+ * (:140-232), Phong / microfacet colour (:485-519), reflected (:527-537) and refracted (:542-641) children; the
+ * returns (:614, :640, :643) are folded from the deepest generation up.  Colours are IEEE double in the reference's
+ * operation order (pow/exp/sin/cos from the device library: a few ulp from the host's).  Work whose result the
+ * reference never uses is skipped (AO of shadowed points or of materials with ambient 0, a reflected ray of weight 0).
+ *
+ * rtmi_material = Render2/ray_tracer.h:23-34 without emission/type; rtmi_light = what Shade reads of a light:
+ * Center(GetBox(light)) and material->emission (shader.cpp:486-489).  Light 0 casts the shadows (shader.cpp:120).
+ * object_materials[k] belongs to sceneObjects[k] = the tri_object ids the scene was created with.
+ * tri_normals: n_tris × 3, the reference's triNormal per ORIGINAL triangle (host pointer, copied).
+ * A shader holds a workspace (at most about RTMI_SHADE_WS_MB, default 4096, MiB; a frame is cut into chunks that
+ * fit): calls on the same shader must not overlap. */
+typedef struct rtmi_material {
+	double diffuse[3], specular[3], ambient[3], reflectivity[3], translucency[3];
+	double phong_exp, ref_index, roughness;
+} rtmi_material;
+typedef struct rtmi_light {
+	double center[3];
+	double emission[3];
+} rtmi_light;
+typedef struct rtmi_trace_params {
+	uint32_t max_tree_depth; /* Scene::max_tree_depth, Render2/base.h:70: 1 */
+	uint32_t ao_rays;        /* shader.cpp:481: 10; 0 = occlusion 1 (shader.cpp:142) */
+	double ao_radius;        /* shader.cpp:481: 2.0 */
+	uint64_t seed;           /* AO square points: stream (seed, ray-tree path, ray index, sample); the reference's are unseeded */
+} rtmi_trace_params;
+typedef struct rtmi_shader rtmi_shader;
+rtmi_shader *rtmi_shader_create(rtmi_scene *, const double *tri_normals, const rtmi_material *object_materials,
+                                uint32_t n_objects, const rtmi_light *lights, uint32_t n_lights);
+void rtmi_shader_destroy(rtmi_shader *);
+/* Color Scene::Trace(const Ray&) on n device-resident rays of the given generation (1 = from the eye,
+ * rasterizer.cpp:217): d_rgb[3k..3k+2] before ToneMap.  Ray k is ray first_index + k of the AO stream.  Inactive
+ * slots are left untouched. */
+int rtmi_trace_dev(rtmi_shader *, const rtmi_ray *d_rays, uint64_t n, uint32_t generation, uint64_t first_index,
+                   const rtmi_trace_params *params, double *d_rgb, void *stream);
+/* The frame of Serial_Normal_Raster: this rank's tiles (as rtmi_primary_closest_hit_dev) of a full frame:
+ * d_rgb[(i·x_res + j)·3 ..] doubles and/or d_pixels[(i·x_res + j)·3 ..] = ToneMap bytes (either may be NULL). */
+int rtmi_render_frame_dev(rtmi_shader *, const rtmi_camera *cam, double sx, double sy, uint32_t tile_w, uint32_t tile_h,
+                          uint32_t tile_first, uint32_t tile_stride, const rtmi_trace_params *params, double *d_rgb,
+                          uint8_t *d_pixels, void *stream);
+/* ToneMap (Render2/rasterizer.cpp:79-88) on n colours -> 3n bytes */
+int rtmi_tone_map_dev(const double *d_rgb, uint64_t n, uint8_t *d_pixels, void *stream);
+
 /* ---- radiosity: form factors ------------------------------------------------------------------------
  * The patches are the scene's triangles (elements = the leaves every visibility ray is tested
  * against, Render2/radiosity.cpp:137-163), so patch i = triangle i of the scene.  verts: n × 9 doubles,

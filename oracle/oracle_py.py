@@ -182,6 +182,25 @@ class Oracle:
                                     _p(B))
         return B, s
 
+    def trace(self, tris, normals, tri_object, mats18, lights6, o, d, max_depth=1, ao_rays=10, ao_radius=2.0, seed=1,
+              generation=1, first_index=0, bvh=None):
+        """rto_trace: Scene::Trace + Shader::Shade on n rays -> n × 3 colours"""
+        tris = _f64(tris, (-1, 9)); normals = _f64(normals, (-1, 3)); mats18 = _f64(mats18, (-1, 18))
+        lights6 = _f64(lights6, (-1, 6)); o = _f64(o, (-1, 3)); d = _f64(d, (-1, 3))
+        tob = np.ascontiguousarray(tri_object, np.uint32)
+        rgb = np.zeros((len(o), 3))
+        self.lib.rto_trace(C.c_long(len(tris)), _p(tris), _p(normals), _p(tob), _p(mats18), _p(lights6),
+                           C.c_int(len(lights6)), bvh, C.c_uint32(max_depth), C.c_uint32(ao_rays), C.c_double(ao_radius),
+                           C.c_uint64(seed), C.c_long(len(o)), _p(o), _p(d), C.c_uint32(generation),
+                           C.c_uint64(first_index), _p(rgb))
+        return rgb
+
+    def tone_map(self, rgb):
+        rgb = _f64(rgb, (-1, 3))
+        out = np.zeros((len(rgb), 3), np.uint8)
+        self.lib.rto_tone_map(C.c_long(len(rgb)), _p(rgb), _p(out))
+        return out
+
     def num_threads(self):
         return self.lib.rto_num_threads()
 
@@ -206,9 +225,9 @@ class Reference:
 
     def __init__(self, path=REF_SO):
         self.lib = L = C.CDLL(path)
-        for f in ("ref_scene_load", "ref_scene_from_triangles"):
+        for f in ("ref_scene_load", "ref_scene_from_triangles", "ref_scene_one_tri_objects"):
             getattr(L, f).restype = C.c_void_p
-        for f in ("ref_cast", "ref_brute", "ref_rad_ff_term", "ref_rad_ff_light_term", "ref_rad_find_form_factor",
+        for f in ("ref_cast", "ref_brute", "ref_trace", "ref_rad_ff_term", "ref_rad_ff_light_term", "ref_rad_find_form_factor",
                   "ref_rad_solve", "ref_rad_residual"):
             getattr(L, f).restype = C.c_double
         L.ref_num_triangles.restype = C.c_long
@@ -237,6 +256,40 @@ class Reference:
         n_obj = int(obj.max()) + 1 if n else 1
         lt = _f64(light) if light is not None else None
         return C.c_void_p(self.lib.ref_scene_from_triangles(_p(tris), _p(obj), C.c_long(n), C.c_int(n_obj), _p(lt)))
+
+    def scene_one_tri_objects(self, tris, normals, mat_of, mats18, lights6):
+        """n one-triangle Objects (Scene::Cast = brute force over the original triangles), see ref_driver.cpp"""
+        tris = _f64(tris, (-1, 9)); mats18 = _f64(mats18, (-1, 18)); lights6 = _f64(lights6, (-1, 6))
+        nr = _f64(normals, (-1, 3)) if normals is not None else None
+        mo = np.ascontiguousarray(mat_of, np.uint32)
+        return C.c_void_p(self.lib.ref_scene_one_tri_objects(_p(tris), _p(nr), C.c_long(len(tris)), _p(mo), _p(mats18),
+                                                             C.c_int(len(mats18)), _p(lights6), C.c_int(len(lights6))))
+
+    def materials(self, h):
+        out = np.zeros((self.lib.ref_num_objects(h), 18))
+        self.lib.ref_get_materials(h, _p(out))
+        return out
+
+    def lights(self, h):
+        out = np.zeros((self.lib.ref_num_lights(h), 6))
+        self.lib.ref_get_lights(h, _p(out))
+        return out
+
+    def set_max_depth(self, h, depth):
+        self.lib.ref_set_max_depth(h, C.c_uint(depth))
+
+    def trace(self, h, o, d, generation=1):
+        """Scene::Trace per ray -> (n × 3 colours, seconds)"""
+        o = _f64(o, (-1, 3)); d = _f64(d, (-1, 3))
+        rgb = np.zeros((len(o), 3))
+        secs = self.lib.ref_trace(h, C.c_long(len(o)), _p(o), _p(d), C.c_uint(generation), _p(rgb))
+        return rgb, secs
+
+    def tone_map(self, rgb):
+        rgb = _f64(rgb, (-1, 3))
+        out = np.zeros((len(rgb), 3), np.uint8)
+        self.lib.ref_tone_map(C.c_long(len(rgb)), _p(rgb), _p(out))
+        return out
 
     def build_bsp(self, h, workdir):
         return self.lib.ref_build_bsp(h, workdir.encode())

@@ -277,6 +277,91 @@ void ref_shadow_rays(long n, const double *P, const double *N, const double *C, 
 	}
 }
 
+// ---------------------------------------------------------------- shading (Scene::Trace / Shader::Shade)
+// A scene of n one-triangle Objects: Object::root is the triangle itself (a BSP leaf), so Object::Intersect
+// (object.cpp:170-184) runs the reference's Möller–Trumbore on the ORIGINAL triangle and Scene::Cast's strict '<'
+// over sceneObjects (scene.cpp:193-205) is brute force — no BSP build, no fragments.  mats: n_mat × 18 doubles
+// (diffuse, specular, ambient, reflectivity, translucency, Phong_exp, ref_index, roughness); lights: n_l × 6
+// (centre of a radius-1 SphereLight, emission).  normals may be NULL (face normal as params.cpp:199-208).
+void *ref_scene_one_tri_objects(const double *xyz, const double *normals, long n, const uint32_t *mat_of, const double *mats,
+                                int n_mat, const double *lights, int n_l) {
+	Quiet q;
+	RefScene *s = new RefScene();
+	s->scene.rasterize = new Rasterizer();
+	std::vector<Material *> M;
+	for (int k = 0; k < n_mat; ++k) {
+		const double *m = mats + 18 * k;
+		Material *mat = new Material();
+		mat->diffuse = Color(m[0], m[1], m[2]); mat->specular = Color(m[3], m[4], m[5]);
+		mat->ambient = Color(m[6], m[7], m[8]); mat->reflectivity = Color(m[9], m[10], m[11]);
+		mat->translucency = Color(m[12], m[13], m[14]); mat->emission = Black;
+		mat->Phong_exp = m[15]; mat->ref_index = m[16]; mat->microFacetsRoughness = m[17];
+		M.push_back(mat);
+	}
+	for (long i = 0; i < n; ++i) {
+		Object *o = new Object();
+		o->nameOfObject = "tri" + std::to_string(i);
+		o->material = M[mat_of[i]];
+		o->triangles.reserve(1);
+		o->triangles.push_back(BSP_Node(BSP_Node::numOfTriangle++));
+		BSP_Node &t = o->triangles.back();
+		t.triVert1 = V(xyz + 9 * i); t.triVert2 = V(xyz + 9 * i + 3); t.triVert3 = V(xyz + 9 * i + 6);
+		t.triNormal = normals ? V(normals + 3 * i) : Unit((t.triVert2 - t.triVert1) ^ (t.triVert3 - t.triVert2));
+		t.left = t.right = NULL;
+		o->root = &t;
+		s->scene.sceneObjects.push_back(o);
+	}
+	for (int k = 0; k < n_l; ++k) {
+		SphereLight *L = new SphereLight(V(lights + 6 * k), 1.0);
+		Material *lm = new Material();
+		lm->emission = Color(lights[6 * k + 3], lights[6 * k + 4], lights[6 * k + 5]);
+		L->material = lm;
+		s->scene.lights.push_back(L);
+	}
+	s->bsp_built = true;
+	return s;
+}
+
+// per sceneObject: the 18 material doubles of ref_scene_one_tri_objects; per light: Center(GetBox) and emission
+void ref_get_materials(void *h, double *out) {
+	long k = 0;
+	for (Object *o : ((RefScene *)h)->scene.sceneObjects) {
+		const Material &m = *o->material;
+		double *p = out + 18 * k++;
+		const Color *c[5] = {&m.diffuse, &m.specular, &m.ambient, &m.reflectivity, &m.translucency};
+		for (int a = 0; a < 5; ++a) { p[3 * a] = c[a]->red; p[3 * a + 1] = c[a]->green; p[3 * a + 2] = c[a]->blue; }
+		p[15] = m.Phong_exp; p[16] = m.ref_index; p[17] = m.microFacetsRoughness;
+	}
+}
+void ref_get_lights(void *h, double *out) {
+	RefScene *s = (RefScene *)h;
+	for (unsigned i = 0; i < s->scene.NumLights(); ++i) {
+		const PrimitiveObject *L = s->scene.GetLight(i);
+		put(out + 6 * i, Center(GetBox(*L)));
+		out[6 * i + 3] = L->material->emission.red; out[6 * i + 4] = L->material->emission.green;
+		out[6 * i + 5] = L->material->emission.blue;
+	}
+}
+void ref_set_max_depth(void *h, unsigned d) { ((RefScene *)h)->scene.max_tree_depth = d; }
+
+// Scene::Trace (scene.cpp:127-155) on n rays of the given generation (1 = from the eye, rasterizer.cpp:217);
+// rgb: n × 3 doubles, before ToneMap.  Ambient occlusion inside Shade draws from an unseeded generator
+// (shader.cpp:148-150): results are reproducible only where the material's ambient is 0.  returns seconds.
+double ref_trace(void *h, long n, const double *o, const double *d, unsigned generation, double *rgb) {
+	RefScene *s = (RefScene *)h;
+	Ray ray;
+	ray.type = generic_ray;
+	ray.generation = generation;
+	double t0 = now_s();
+	for (long k = 0; k < n; ++k) {
+		ray.origin = V(o + 3 * k);
+		ray.direction = V(d + 3 * k);
+		Color c = s->scene.Trace(ray);
+		rgb[3 * k] = c.red; rgb[3 * k + 1] = c.green; rgb[3 * k + 2] = c.blue;
+	}
+	return now_s() - t0;
+}
+
 // ---------------------------------------------------------------- radiosity
 // Sets the public fields the constructor sets (radiosity.cpp:23-44) and runs
 // findIntersections + buildInitialQuadTree.  Returns numOfElements (= BSP leaves).

@@ -15,3 +15,11 @@ extern "C" void ref_raster_details_impl(Scene *scene, Camera *cam, double *out18
 	const Vec3 *v[6] = {&rd.G, &rd.U, &rd.R, &rd.O, &rd.dR, &rd.dU};
 	for (int k = 0; k < 6; ++k) { out18[3 * k] = v[k]->x; out18[3 * k + 1] = v[k]->y; out18[3 * k + 2] = v[k]->z; }
 }
+
+// ToneMap (rasterizer.cpp:79-88, file-static) on n colours -> n × 3 bytes
+extern "C" void ref_tone_map(long n, const double *rgb, unsigned char *out) {
+	for (long k = 0; k < n; ++k) {
+		Pixel p = ToneMap(Color(rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]));
+		out[3 * k] = p.r; out[3 * k + 1] = p.g; out[3 * k + 2] = p.b;
+	}
+}

@@ -607,45 +607,48 @@ static inline int box_hit(const bnode *n, v3 o, v3 inv, double tbest, double *tn
 	return t0 <= t1;
 }
 
+/* one ray through the BVH: same winner as the in-order scan (smaller t, or equal t and smaller index) */
+static int32_t bvh_closest_one(const rto_bvh *b, v3 O, v3 D, double tmax, double *bt, double *pu, double *pv) {
+	v3 inv = {1.0 / D.x, 1.0 / D.y, 1.0 / D.z};
+	double best = tmax, bu = 0, bv = 0;
+	int32_t bi = -1;
+	int32_t stack[128];
+	int sp = 0;
+	if (b->n_tris > 0) stack[sp++] = 0;
+	while (sp) {
+		const bnode *n = &b->nodes[stack[--sp]];
+		double tn;
+		if (!box_hit(n, O, inv, best, &tn)) continue;
+		if (n->left < 0) {
+			for (int32_t i = n->first; i < n->first + n->count; ++i) {
+				int32_t id = b->order[i];
+				const double *p = b->tris + 9 * (long)id;
+				double uu = 0, vv = 0;
+				double tt = mt(O, D, ld3(p), ld3(p + 3), ld3(p + 6), &uu, &vv);
+				if (tt > 0.0 && (best > tt || (bi >= 0 && best == tt && id < bi))) { best = tt; bi = id; bu = uu; bv = vv; }
+			}
+		} else {
+			double t0, t1;
+			int h0 = box_hit(&b->nodes[n->left], O, inv, best, &t0);
+			int h1 = box_hit(&b->nodes[n->right], O, inv, best, &t1);
+			if (h0 && h1) {
+				if (t0 <= t1) { stack[sp++] = n->right; stack[sp++] = n->left; }
+				else { stack[sp++] = n->left; stack[sp++] = n->right; }
+			} else if (h0) stack[sp++] = n->left;
+			else if (h1) stack[sp++] = n->right;
+		}
+	}
+	*bt = bi >= 0 ? best : 0.0; *pu = bu; *pv = bv;
+	return bi;
+}
+
 double rto_bvh_closest_hit(const rto_bvh *b, long n_rays, const double *o, const double *d, const double *tmax,
                            int32_t *tri, double *t, double *u, double *v) {
 	struct timespec a, z;
 	clock_gettime(CLOCK_MONOTONIC, &a);
 #pragma omp parallel for schedule(dynamic, 256)
-	for (long k = 0; k < n_rays; ++k) {
-		v3 O = ld3(o + 3 * k), D = ld3(d + 3 * k);
-		v3 inv = {1.0 / D.x, 1.0 / D.y, 1.0 / D.z};
-		double best = tmax ? tmax[k] : RTO_INFINITY, bu = 0, bv = 0;
-		int32_t bi = -1;
-		int32_t stack[128];
-		int sp = 0;
-		if (b->n_tris > 0) stack[sp++] = 0;
-		while (sp) {
-			const bnode *n = &b->nodes[stack[--sp]];
-			double tn;
-			if (!box_hit(n, O, inv, best, &tn)) continue;
-			if (n->left < 0) {
-				for (int32_t i = n->first; i < n->first + n->count; ++i) {
-					int32_t id = b->order[i];
-					const double *p = b->tris + 9 * (long)id;
-					double uu = 0, vv = 0;
-					double tt = mt(O, D, ld3(p), ld3(p + 3), ld3(p + 6), &uu, &vv);
-					/* same winner as the in-order scan: smaller t, or equal t and smaller index */
-					if (tt > 0.0 && (best > tt || (bi >= 0 && best == tt && id < bi))) { best = tt; bi = id; bu = uu; bv = vv; }
-				}
-			} else {
-				double t0, t1;
-				int h0 = box_hit(&b->nodes[n->left], O, inv, best, &t0);
-				int h1 = box_hit(&b->nodes[n->right], O, inv, best, &t1);
-				if (h0 && h1) {
-					if (t0 <= t1) { stack[sp++] = n->right; stack[sp++] = n->left; }
-					else { stack[sp++] = n->left; stack[sp++] = n->right; }
-				} else if (h0) stack[sp++] = n->left;
-				else if (h1) stack[sp++] = n->right;
-			}
-		}
-		tri[k] = bi; t[k] = bi >= 0 ? best : 0.0; u[k] = bu; v[k] = bv;
-	}
+	for (long k = 0; k < n_rays; ++k)
+		tri[k] = bvh_closest_one(b, ld3(o + 3 * k), ld3(d + 3 * k), tmax ? tmax[k] : RTO_INFINITY, &t[k], &u[k], &v[k]);
 	clock_gettime(CLOCK_MONOTONIC, &z);
 	return (double)(z.tv_sec - a.tv_sec) + 1e-9 * (double)(z.tv_nsec - a.tv_nsec);
 }
@@ -656,4 +659,158 @@ int rto_num_threads(void) {
 #else
 	return 1;
 #endif
+}
+
+/* ---- Scene::Trace + Shader::Shade (scene.cpp:127-155, shader.cpp:395-645), the branch the shipped
+ * main.cpp runs (scene.radiosity == NULL) ------------------------------------------------------- */
+typedef struct {
+	long n_tris;
+	const double *tris, *normals, *mats, *lights;
+	const uint32_t *tri_object;
+	int n_lights;
+	const rto_bvh *bvh;
+	uint32_t max_depth, ao_rays;
+	double ao_radius;
+	uint64_t seed;
+} shade_ctx;
+
+static const v3 kBackground = {0.15, 0.25, 0.35}; /* scene.cpp:21 */
+static const v3 kTermination = {0.0, 0.0, 0.0};   /* scene.cpp:22 */
+
+static inline v3 cmul(v3 a, v3 b) { v3 r = {a.x * b.x, a.y * b.y, a.z * b.z}; return r; } /* color.h:43 */
+static inline double max2(double x, double y) { return x >= y ? x : y; }                /* util.h:26 */
+static inline double min3(double x, double y, double z) {                              /* util.cpp:7 */
+	if (x <= y && x <= z) return x;
+	if (y <= z) return y;
+	return z;
+}
+
+static int32_t cast(const shade_ctx *c, v3 O, v3 D, double tmax, double *t) {
+	double u, v;
+	if (c->bvh) return bvh_closest_one(c->bvh, O, D, tmax, t, &u, &v);
+	return closest(c->n_tris, c->tris, O, D, tmax, t, &u, &v);
+}
+
+/* findOcclusionNew (shader.cpp:140-232); square points of stream (mix64(seed ^ path), k0, sample) */
+static double occlusion(const shade_ctx *c, v3 P, v3 normal, uint64_t k0, uint64_t path) {
+	if (c->ao_rays == 0) return 1;                       /* :142 */
+	int occ = 0;
+	v3 X, Y, Z;
+	ao_frame(normal, &X, &Y, &Z);
+	const uint64_t node_seed = mix64(c->seed ^ path);
+	for (uint32_t s = 0; s < c->ao_rays; ++s) {
+		double ab[2], t;
+		v3 o, d;
+		rto_ao_square_point(node_seed, k0, s, ab);
+		ao_ray(P, X, Y, Z, c->ao_radius, ab[0], ab[1], &o, &d);
+		if (cast(c, o, d, c->ao_radius, &t) >= 0) occ++;  /* :226  Cast ∧ distance < R */
+	}
+	return (1.0 - (occ / (double)c->ao_rays));           /* :231 */
+}
+
+static v3 trace_rec(const shade_ctx *c, v3 O, v3 D, uint32_t generation, uint64_t k0, uint64_t path);
+
+static v3 shade(const shade_ctx *c, v3 O, v3 D, int32_t tri, double distance, uint32_t generation, uint64_t k0,
+                uint64_t path) {
+	const double *m = c->mats + 18 * (size_t)(c->tri_object ? c->tri_object[tri] : 0);
+	const v3 diffuse = ld3(m), specular = ld3(m + 3), ambient = ld3(m + 6), reflective = ld3(m + 9);
+	v3 transl = ld3(m + 12);
+	const double e = m[15], k = m[16], rough = m[17];
+	const v3 Ns = ld3(c->normals + 3 * (size_t)tri);     /* hit.normal = triNormal, object.cpp:17 */
+	const v3 P = hit_point(O, D, ld3(c->tris + 9 * (size_t)tri), Ns);
+	const v3 N = unit(Ns);                               /* :416 */
+	const v3 E = unit(sub(O, P));                        /* :417 */
+	v3 R;
+	v3 color = {0, 0, 0};                                /* :427-429 */
+
+	const double occ = occlusion(c, P, Ns, k0, path);    /* :481 */
+	for (int i = 0; i < c->n_lights; ++i) {              /* :485-519 */
+		const v3 LightPos = ld3(c->lights + 6 * i), emission = ld3(c->lights + 6 * i + 3);
+		const v3 L = unit(sub(LightPos, P));
+		color = add(color, cmul(emission, add(scl(.85 * occ, ambient), scl(max2(0, dot(N, L)), diffuse)))); /* :494 */
+		if (rough != 0.0) {                              /* :496-508 */
+			const v3 H = unit(add(L, E));
+			const double LH = dot(L, H), NH = dot(N, H);
+			const double g = sqrt((30.0 * 3016.0) - 1.0 + (LH * LH));
+			double Fresnel = 0.5 * pow(g - LH, 2) / pow(g + LH, 2);
+			Fresnel *= pow(LH * (g + LH) - 1.0, 2) / pow(LH * (g - LH) + 1.0, 2) + 1.0;
+			const double mm = 0.4;
+			double Dm = 1.0 / (4.0 * mm * mm * pow(NH, 4));
+			const double DPow = (pow(NH, 2) - 1.0) / ((mm * mm) * pow(NH, 2));
+			Dm = pow(Dm, DPow);
+			const double G = min3(1.0, (2.0 * NH * NH) / LH, (2.0 * NH * dot(N, L)) / LH);
+			const double kk = .7;
+			color = add(color, scl((Fresnel * Dm * G) / (RTO_PI * dot(N, E) * dot(N, L)), scl(kk, specular)));
+		} else {                                         /* :510-518 */
+			const v3 RR = add(scl(-1.0, L), scl(2.0 * dot(L, N), N));
+			color = add(color, cmul(emission, scl(pow(max2(0.0, dot(E, RR)), e), specular)));
+		}
+	}
+	{                                                    /* generateNormalShadows, :105-138 */
+		const v3 dir = unit(sub(ld3(c->lights), P));
+		const v3 org = add(P, scl(0.01, Ns));
+		double t;
+		if (cast(c, org, dir, RTO_INFINITY, &t) >= 0) color = scl(0.7, ambient);
+	}
+
+	R = add(scl(-1.0, E), scl(2.0 * dot(E, Ns), Ns));    /* :532 */
+	if (transl.z > 0.0 && transl.y > 0.0 && transl.x > 0.0) { /* :542 */
+		double refractionCoef = 0;
+		v3 tRefr = {0, 0, 0};
+		const v3 mE = scl(-1, E), mN = scl(-1, Ns);
+		if (dot(E, Ns) < 0.0) R = add(scl(-1.0, E), scl(2.0 * dot(E, mN), mN)); /* :571-574 */
+		else R = add(scl(-1.0, E), scl(2.0 * dot(E, Ns), Ns));
+		if (dot(mE, Ns) < 0.0) {                         /* :576-588 */
+			const double dn = dot(mE, Ns);
+			const v3 cosRefract = divs(sub(mE, scl(dn, Ns)), k);
+			const double cosSq = 1 - ((1 - (dn * dn)) / (k * k));
+			tRefr = sub(cosRefract, scl(sqrt(cosSq), Ns));
+			refractionCoef = dot(E, Ns);
+			transl.x = transl.y = transl.z = 1;
+		} else {                                         /* :589-625 */
+			transl.x = exp(-1.0 * transl.x * distance);
+			transl.y = exp(-1.0 * transl.y * distance);
+			transl.z = exp(-1.0 * transl.z * distance);
+			const double dn = dot(mE, mN);
+			const v3 cosRefract = divs(sub(mE, scl(dn, mN)), k);
+			const double cosSq = 1 - ((1 - (dn * dn)) / (k * k));
+			if (cosSq < 0.0)                             /* :608-615 total internal reflection */
+				return cmul(transl, trace_rec(c, add(P, scl(RTO_EPSILON, R)), R, generation + 1, k0, 2 * path));
+			tRefr = sub(cosRefract, scl(sqrt(cosSq), mN));
+			refractionCoef = dot(tRefr, Ns);
+		}
+		const double beerR0 = ((1 - k) * (1 - k)) / ((1 + k) * (1 + k));          /* :627 */
+		const double beerR = beerR0 + (1 - beerR0) * pow(1 - refractionCoef, 5);  /* :628 */
+		const v3 a = trace_rec(c, add(P, scl(RTO_EPSILON, R)), R, generation + 1, k0, 2 * path);
+		const v3 b = trace_rec(c, add(P, scl(RTO_EPSILON, tRefr)), tRefr, generation + 1, k0, 2 * path + 1);
+		return cmul(transl, add(scl(beerR, a), scl(1 - beerR, b)));               /* :640 */
+	}
+	return add(color, cmul(reflective, trace_rec(c, add(P, scl(RTO_EPSILON, R)), R, generation + 1, k0, 2 * path))); /* :643 */
+}
+
+static v3 trace_rec(const shade_ctx *c, v3 O, v3 D, uint32_t generation, uint64_t k0, uint64_t path) {
+	if (generation > c->max_depth) return kTermination;  /* scene.cpp:134-137 */
+	double t;
+	const int32_t tri = cast(c, O, D, RTO_INFINITY, &t);
+	if (tri < 0) return kBackground;                     /* scene.cpp:151 */
+	return shade(c, O, D, tri, t, generation, k0, path);
+}
+
+void rto_trace(long n_tris, const double *tris, const double *normals, const uint32_t *tri_object, const double *mats18,
+               const double *lights6, int n_lights, const rto_bvh *bvh, uint32_t max_tree_depth, uint32_t ao_rays,
+               double ao_radius, uint64_t seed, long n_rays, const double *o, const double *d, uint32_t generation,
+               uint64_t first_index, double *rgb) {
+	shade_ctx c = {n_tris, tris, normals, mats18, lights6, tri_object, n_lights, bvh, max_tree_depth, ao_rays,
+	               ao_radius, seed};
+#pragma omp parallel for schedule(dynamic, 64)
+	for (long k = 0; k < n_rays; ++k)
+		st3(rgb + 3 * k, trace_rec(&c, ld3(o + 3 * k), ld3(d + 3 * k), generation, first_index + (uint64_t)k, 1));
+}
+
+/* ToneMap, rasterizer.cpp:79-88 */
+void rto_tone_map(long n, const double *rgb, uint8_t *out) {
+	for (long k = 0; k < 3 * n; ++k) {
+		int c = (int)floor(256 * rgb[k]);
+		out[k] = (uint8_t)(c >= 255 ? 255 : c);
+	}
 }

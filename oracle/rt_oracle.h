@@ -128,6 +128,20 @@ double rto_bvh_closest_hit(const rto_bvh *, long n_rays, const double *o, const 
                            int32_t *tri, double *t, double *u, double *v);
 int rto_num_threads(void);
 
+/* ---- Scene::Trace + Shader::Shade (scene.cpp:127-155, shader.cpp:395-645; the scene.radiosity == NULL branch) ----
+ * mats18: per object {diffuse, specular, ambient, reflectivity, translucency}[3] + Phong_exp, ref_index, roughness;
+ * lights6: per light {Center(GetBox(light)), emission}; normals = triNormal per triangle; bvh may be NULL (in-order
+ * scan).  Ray k has index first_index + k; the AO square points of the node reached from it along `path` (1 = the ray
+ * itself, 2p = reflected / totally reflected child of p, 2p+1 = refracted child) come from
+ * rto_ao_square_point(mix64(seed ^ path), index, sample) where the reference draws from an unseeded mt19937.
+ * rgb: n_rays × 3 doubles before ToneMap. */
+void rto_trace(long n_tris, const double *tris, const double *normals, const uint32_t *tri_object, const double *mats18,
+               const double *lights6, int n_lights, const rto_bvh *bvh, uint32_t max_tree_depth, uint32_t ao_rays,
+               double ao_radius, uint64_t seed, long n_rays, const double *o, const double *d, uint32_t generation,
+               uint64_t first_index, double *rgb);
+/* rasterizer.cpp:79-88 */
+void rto_tone_map(long n, const double *rgb, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

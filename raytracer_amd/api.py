@@ -7,6 +7,8 @@ names and argument meaning so that tests read like calls into the reference:
     Scene.Cast(rays) -> hit records       Render2/scene.cpp:159   -> rtmi_closest_hit[_dev]
     Scene.Occluded(rays)                  Render2/shader.cpp:131  -> rtmi_any_hit[_dev]
     Rasterizer.RasterDetails / Rasterize  Render2/rasterizer.cpp  -> rtmi_camera_setup, rtmi_primary_*
+    Shader(scene,...).Trace(rays)         Render2/scene.cpp:127 + shader.cpp:395 -> rtmi_trace_dev
+    Shader(scene,...).Rasterize(camera)   Render2/rasterizer.cpp:148-241        -> rtmi_render_frame_dev
     Radiosity.isVisibleXiToXj             Render2/radiosity.cpp:231
     Radiosity.findFormFactor              Render2/radiosity.cpp:335
     Radiosity.progressiveRefinement       Render2/radiosity.cpp:483 (same fixed point, Jacobi sweeps)
@@ -50,6 +52,14 @@ class rtmi_solve_stats(C.Structure):
                 ("bytes_per_sweep", C.c_double)]
 
 
+class rtmi_trace_params(C.Structure):
+    _fields_ = [("max_tree_depth", C.c_uint32), ("ao_rays", C.c_uint32), ("ao_radius", C.c_double), ("seed", C.c_uint64)]
+
+
+# include/rtmi.h: rtmi_material (18 doubles), rtmi_light (6 doubles)
+MATERIAL_DOUBLES = 18
+LIGHT_DOUBLES = 6
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 
 # every symbol include/rtmi.h declares (tests check the library exports exactly these)
@@ -59,6 +69,7 @@ SYMBOLS = [
     "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev",
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev",
+    "rtmi_shader_create", "rtmi_shader_destroy", "rtmi_trace_dev", "rtmi_render_frame_dev", "rtmi_tone_map_dev",
 ]
 
 
@@ -95,6 +106,14 @@ def _load():
     L.rtmi_jacobi_sweep_dev.argtypes = [vp, u64, u32, u32, u32, vp, vp, vp, vp, vp, vp]
     L.rtmi_radiosity_solve_dev.argtypes = [vp, u64, u32, u32, u32, vp, vp, vp, C.c_float, u32, u32, vp, vp,
                                            C.POINTER(rtmi_solve_stats), vp]
+    L.rtmi_shader_create.restype = vp
+    L.rtmi_shader_create.argtypes = [vp, vp, vp, u32, vp, u32]
+    L.rtmi_shader_destroy.argtypes = [vp]
+    L.rtmi_shader_destroy.restype = None
+    L.rtmi_trace_dev.argtypes = [vp, vp, u64, u32, u64, C.POINTER(rtmi_trace_params), vp, vp]
+    L.rtmi_render_frame_dev.argtypes = [vp, C.POINTER(rtmi_camera), dbl, dbl, u32, u32, u32, u32,
+                                        C.POINTER(rtmi_trace_params), vp, vp, vp]
+    L.rtmi_tone_map_dev.argtypes = [vp, u64, vp, vp]
     return L
 
 
@@ -251,6 +270,81 @@ def occlusion_fraction_dev(d_occluded, n, spp, d_out, stream=0):
 
 def primary_rays_dev(cam, d_rays, sx=0.5, sy=0.5, stream=0):
     _check(lib.rtmi_primary_rays_dev(C.byref(cam.c), sx, sy, d_rays, stream))
+
+
+class Shader:
+    """Scene::Trace + Shader::Shade (scene.cpp:127-155, shader.cpp:395-645) and the pixel loop of
+    Rasterizer::Rasterize (rasterizer.cpp:148-241), as one wavefront on the device.
+    normals: n_tris x 3 (triNormal); materials: n_objects x 18 (diffuse, specular, ambient, reflectivity, translucency,
+    Phong_exp, ref_index, roughness); lights: n_lights x 6 (Center(GetBox(light)), emission)."""
+
+    def __init__(self, scene, normals, materials, lights, max_tree_depth=1, ao_rays=10, ao_radius=2.0, seed=1):
+        self.scene = scene
+        nrm = _np(normals, np.float64, (-1, 3))
+        mats = _np(materials, np.float64, (-1, MATERIAL_DOUBLES))
+        lts = _np(lights, np.float64, (-1, LIGHT_DOUBLES))
+        if len(nrm) != len(scene.tri_xyz):
+            raise ValueError("one normal per triangle of the scene")
+        self.handle = None
+        h = lib.rtmi_shader_create(scene.handle, _ptr(nrm), _ptr(mats), len(mats), _ptr(lts), len(lts))
+        if not h:
+            raise RtmiError(lib.rtmi_last_error().decode())
+        self.handle = C.c_void_p(h)
+        self.params = rtmi_trace_params(int(max_tree_depth), int(ao_rays), float(ao_radius), int(seed))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib.rtmi_shader_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def trace_dev(self, d_rays, n, d_rgb, generation=1, first_index=0, stream=0):
+        _check(lib.rtmi_trace_dev(self.handle, d_rays, n, generation, first_index, C.byref(self.params), d_rgb, stream))
+
+    def render_frame_dev(self, cam, d_rgb, d_pixels, sx=0.5, sy=0.5, tile=(0, 0), tile_first=0, tile_stride=1, stream=0):
+        _check(lib.rtmi_render_frame_dev(self.handle, C.byref(cam.c), sx, sy, tile[0], tile[1], tile_first, tile_stride,
+                                         C.byref(self.params), d_rgb, d_pixels, stream))
+
+    # -- host-buffer conveniences (torch owns the device memory) --
+    def Trace(self, rays, generation=1, first_index=0):
+        """Color Scene::Trace(ray) for a batch of RAY_DTYPE records -> n x 3 doubles (before ToneMap)."""
+        import torch
+        rays = _np(rays, RAY_DTYPE)
+        n = len(rays)
+        d_rays = torch.from_numpy(rays.view(np.uint8).reshape(n, 64).copy()).cuda()
+        d_rgb = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+        self.trace_dev(d_rays.data_ptr(), n, d_rgb.data_ptr(), generation, first_index, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return d_rgb.cpu().numpy()
+
+    def Rasterize(self, cam, sx=0.5, sy=0.5, tile=(0, 0), tile_first=0, tile_stride=1):
+        """Rasterizer::Rasterize: returns (rgb y_res x x_res x 3 doubles, pixels y_res x x_res x 3 uint8 = ToneMap)."""
+        import torch
+        n = cam.x_res * cam.y_res
+        d_rgb = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+        d_pix = torch.zeros(n, 3, dtype=torch.uint8, device="cuda")
+        self.render_frame_dev(cam, d_rgb.data_ptr(), d_pix.data_ptr(), sx, sy, tile, tile_first, tile_stride,
+                              torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return (d_rgb.cpu().numpy().reshape(cam.y_res, cam.x_res, 3), d_pix.cpu().numpy().reshape(cam.y_res, cam.x_res, 3))
+
+
+def tone_map_dev(d_rgb, n, d_pixels, stream=0):
+    """ToneMap (rasterizer.cpp:79-88)."""
+    _check(lib.rtmi_tone_map_dev(d_rgb, n, d_pixels, stream))
+
+
+def write_ppm(path, pixels):
+    """PPM_Image::Write (ppm_image.cpp): binary P6, maxval 255."""
+    px = np.ascontiguousarray(pixels, np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (px.shape[1], px.shape[0]))
+        f.write(px.tobytes())
 
 
 class Radiosity:

@@ -15,6 +15,7 @@ struct rtmi_scene {
 	int *d_queue;                     // ring of work-queue counters, one per launch in flight (kQueueSlots)
 	std::atomic<uint32_t> next_slot;
 	int n_cus;
+	uint32_t n_objects; // 1 + the largest tri_object seen at creation (materials are looked up by it)
 	double *d_v1_orig; // n_tris × 3: triVert1 of every triangle in ORIGINAL order (hit points, object.cpp:23)
 };
 

@@ -1,0 +1,538 @@
+// librtmi — Scene::Trace + Shader::Shade as a wavefront on the device: the caller of the ray queries, so that a whole
+// frame (primary hits, shadow and ambient-occlusion rays, reflected and refracted generations, colours, ToneMap) never
+// leaves HBM.  Reference: Render2/scene.cpp:127-155 (Trace), Render2/shader.cpp:395-645 (Shade, the branch main.cpp
+// runs: scene.radiosity == NULL), :105-138 (generateNormalShadows), :140-232 (findOcclusionNew),
+// Render2/rasterizer.cpp:79-88 (ToneMap), :219-233 (the pixel loop).  All colour arithmetic is IEEE double in the
+// reference's operation order; pow/exp/sin/cos are the device library's, so colours agree with the reference to a
+// few ulp, not to the bit (hit ids, shadow and occlusion bits are exact).  gfx950 only.
+//
+// The reference recurses per pixel; here one generation of the ray tree is one batch:
+//   closest hit -> k_shade_pre (hit point, shadow ray, refraction children) -> any hit (shadow)
+//   -> k_node_ao_rays -> any hit (AO) -> k_shade_post (colour, reflection child) -> next generation ... -> k_fold
+// Slot s of generation g has its children at slots branch·s (+1) of generation g+1; branch = 2 if any material
+// refracts, else 1.  Work the reference does but whose result it never uses is skipped: AO where the point is shadowed
+// or the material's ambient is 0, local colour of refracting materials, a reflected ray whose weight is 0.
+#include <vector>
+
+#include "rtmi_host.hpp"
+
+struct rtmi_shader {
+	rtmi_scene *scene;
+	double *d_normals;
+	rtmi_material *d_mats;
+	rtmi_light *d_lights;
+	uint32_t n_objects, n_lights;
+	bool any_translucent, any_ambient;
+	char *ws;        // grow-only workspace
+	size_t ws_bytes;
+};
+
+namespace rtmi {
+
+struct ShadeDev {
+	const double *v1_orig, *normals;
+	const rtmi_material *mats;
+	const rtmi_light *lights;
+	uint32_t n_lights;
+};
+
+enum : uint32_t { kDead = 0, kFinal = 1, kOpaque = 2, kReflect = 3, kRefract = 4, kTir = 5 };
+struct Node { // 64 bytes per slot
+	double c[3];    // colour (local until folded, then final)
+	double coef[3]; // reflectivity (kReflect) or translucency weights (kRefract, kTir)
+	double beer;    // Schlick weight of the reflected child (kRefract)
+	uint32_t kind, pad;
+};
+
+constexpr double kEpsilon = 1.0e-5; // Render2/base.h:57
+__device__ __forceinline__ D3 background() { return d3(0.15, 0.25, 0.35); } // scene.cpp:21
+__device__ __forceinline__ D3 termination() { return d3(0.0, 0.0, 0.0); }   // scene.cpp:22
+__device__ __forceinline__ D3 ld(const double *p) { return d3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st(double *p, D3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ D3 cmul(D3 a, D3 b) { return d3(a.x * b.x, a.y * b.y, a.z * b.z); } // color.h:43
+__device__ __forceinline__ double max2(double x, double y) { return x >= y ? x : y; }         // util.h:26
+__device__ __forceinline__ double min3(double x, double y, double z) {                       // util.cpp:7
+	if (x <= y && x <= z) return x;
+	if (y <= z) return y;
+	return z;
+}
+__device__ __forceinline__ bool refracts(const rtmi_material &m) { // shader.cpp:542
+	return m.translucency[2] > 0.0 && m.translucency[1] > 0.0 && m.translucency[0] > 0.0;
+}
+__device__ __forceinline__ bool nonzero(const double *c) { return c[0] != 0.0 || c[1] != 0.0 || c[2] != 0.0; }
+
+// Generation-1 rays of a frame, rasterizer.cpp:230.  Items enumerate this rank's tiles (tile_first, + tile_stride, ...),
+// 8×8-pixel squares inside a tile when its sides allow; items that fall outside the frame are inactive slots.
+struct FrameGrid { uint32_t tile_w, tile_h, tiles_x, tile_first, tile_stride; };
+__device__ __forceinline__ bool frame_pixel(const FrameGrid &g, const rtmi_camera &cam, uint64_t item, uint32_t &i, uint32_t &j) {
+	const uint32_t per_tile = g.tile_w * g.tile_h;
+	const uint32_t tile = g.tile_first + (uint32_t)(item / per_tile) * g.tile_stride, k = (uint32_t)(item % per_tile);
+	uint32_t lx, ly;
+	if (((g.tile_w | g.tile_h) & 7u) == 0) {
+		const uint32_t sq = k >> 6, in = k & 63u, sq_x = g.tile_w >> 3;
+		lx = (sq % sq_x) * 8 + (in & 7u);
+		ly = (sq / sq_x) * 8 + (in >> 3);
+	} else {
+		lx = k % g.tile_w;
+		ly = k / g.tile_w;
+	}
+	j = (tile % g.tiles_x) * g.tile_w + lx;
+	i = (tile / g.tiles_x) * g.tile_h + ly;
+	return j < cam.x_res && i < cam.y_res;
+}
+__global__ void k_frame_rays(rtmi_camera cam, double sx, double sy, FrameGrid g, uint64_t item0, uint64_t n,
+                             rtmi_ray *__restrict__ rays, uint64_t *__restrict__ root) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	uint32_t i, j;
+	rtmi_ray R;
+	if (frame_pixel(g, cam, item0 + k, i, j)) {
+		const D3 O = ld(cam.O), dR = ld(cam.dR), dU = ld(cam.dU);
+		set_ray(R, ld(cam.eye), unit((O + (j + sx) * dR) - (i + sy) * dU), RTMI_INFINITY);
+		root[k] = (uint64_t)i * cam.x_res + j;
+	} else {
+		inactive(R);
+		root[k] = ~0ull;
+	}
+	rays[k] = R;
+}
+__global__ void k_batch_roots(uint64_t first, uint64_t n, uint64_t *__restrict__ root) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < n) root[k] = first + k;
+}
+
+// Everything of Shade that needs no secondary-ray answer: classify the slot, refraction (shader.cpp:542-641), the
+// shadow ray (:116-127).  `last`: the children would be generation max_tree_depth+1, for which Trace returns the
+// termination colour without casting (scene.cpp:134-137), so they are folded in at once.
+__global__ void k_shade_pre(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits, uint64_t n,
+                            int last, uint32_t branch, Node *__restrict__ nodes, rtmi_ray *__restrict__ shadow,
+                            rtmi_ray *__restrict__ child) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	Node nd;
+	nd.c[0] = nd.c[1] = nd.c[2] = 0.0; nd.coef[0] = nd.coef[1] = nd.coef[2] = 0.0; nd.beer = 0.0; nd.kind = kDead; nd.pad = 0;
+	rtmi_ray sh, c0, c1;
+	inactive(sh); inactive(c0); inactive(c1);
+	bool write_children = !last;
+	const rtmi_ray r = rays[k];
+	if (r.reserved == 0.0) {
+		const rtmi_hit h = hits[k];
+		if (h.tri == RTMI_MISS) {
+			nd.kind = kFinal;
+			st(nd.c, background()); // scene.cpp:151
+		} else {
+			const rtmi_material m = S.mats[h.object];
+			const D3 Ns = ld(S.normals + 3 * (size_t)h.tri); // hit.normal = triNormal, object.cpp:17
+			const D3 P = hit_point(r, S.v1_orig + 3 * (size_t)h.tri, Ns);
+			if (refracts(m)) {
+				const double kk = m.ref_index;
+				const D3 E = unit(ld(r.o) - P); // :417
+				D3 transl = ld(m.translucency);
+				const D3 mE = -1.0 * E, mN = -1.0 * Ns;
+				D3 R, tRefr = d3(0, 0, 0);
+				double refractionCoef = 0;
+				bool tir = false;
+				if (dot(E, Ns) < 0.0) R = (-1.0 * E) + ((2.0 * dot(E, mN)) * mN); // :571-574
+				else R = (-1.0 * E) + ((2.0 * dot(E, Ns)) * Ns);
+				if (dot(mE, Ns) < 0.0) { // :576-588
+					const double dn = dot(mE, Ns);
+					const D3 cosRefract = (mE - (dn * Ns)) / kk;
+					const double cosSq = 1 - ((1 - (dn * dn)) / (kk * kk));
+					tRefr = cosRefract - (sqrt(cosSq) * Ns);
+					refractionCoef = dot(E, Ns);
+					transl = d3(1, 1, 1);
+				} else { // :589-625
+					transl = d3(exp(-1.0 * transl.x * h.t), exp(-1.0 * transl.y * h.t), exp(-1.0 * transl.z * h.t));
+					const double dn = dot(mE, mN);
+					const D3 cosRefract = (mE - (dn * mN)) / kk;
+					const double cosSq = 1 - ((1 - (dn * dn)) / (kk * kk));
+					if (cosSq < 0.0) tir = true; // :608-615
+					else {
+						tRefr = cosRefract - (sqrt(cosSq) * mN);
+						refractionCoef = dot(tRefr, Ns);
+					}
+				}
+				st(nd.coef, transl);
+				if (tir) {
+					if (last) { nd.kind = kFinal; st(nd.c, cmul(transl, termination())); }
+					else { nd.kind = kTir; set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY); }
+				} else {
+					const double beerR0 = ((1 - kk) * (1 - kk)) / ((1 + kk) * (1 + kk));         // :627
+					const double beerR = beerR0 + (1 - beerR0) * pow(1 - refractionCoef, 5.0); // :628
+					nd.beer = beerR;
+					if (last) {
+						nd.kind = kFinal;
+						st(nd.c, cmul(transl, (beerR * termination()) + ((1 - beerR) * termination()))); // :640
+					} else {
+						nd.kind = kRefract;
+						set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY);         // :630-633
+						set_ray(c1, P + (kEpsilon * tRefr), tRefr, RTMI_INFINITY); // :635-638
+					}
+				}
+			} else {
+				nd.kind = kOpaque; // colour and reflection: k_shade_post
+				write_children = false;
+				set_ray(sh, P + (0.01 * Ns), unit(ld(S.lights[0].center) - P), RTMI_INFINITY); // :122,127
+			}
+		}
+	}
+	nodes[k] = nd;
+	shadow[k] = sh;
+	if (write_children) {
+		child[k * branch] = c0;
+		if (branch == 2) child[k * branch + 1] = c1;
+	}
+}
+
+// findOcclusionNew's rays (shader.cpp:140-232) for the slots that will use the answer.  Square points: stream
+// (mix64(seed ^ path), root ray index, sample); path = 1 for the traced ray itself, 2p / 2p+1 for the children of p.
+__global__ void k_node_ao_rays(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
+                               const Node *__restrict__ nodes, const uint8_t *__restrict__ shadowed,
+                               const uint64_t *__restrict__ root, uint64_t n, uint32_t per_root, uint64_t path0, uint32_t spp,
+                               double R, uint64_t seed, rtmi_ray *__restrict__ out) {
+	const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= n * spp) return;
+	const uint64_t k = idx / spp;
+	const uint32_t s = (uint32_t)(idx % spp);
+	rtmi_ray q;
+	inactive(q);
+	if (nodes[k].kind == kOpaque && !shadowed[k]) {
+		const rtmi_hit h = hits[k];
+		if (nonzero(S.mats[h.object].ambient)) {
+			const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
+			const D3 P = hit_point(rays[k], S.v1_orig + 3 * (size_t)h.tri, Ns);
+			const uint64_t path = path0 + (per_root > 1 ? k % per_root : 0);
+			const uint64_t hsh = wf_mix64(wf_mix64(wf_mix64(seed ^ path) ^ root[k / per_root]) ^ (uint64_t)s);
+			D3 org, dir;
+			ao_ray(P, Ns, R, hsh, org, dir);
+			set_ray(q, org, dir, R); // occluded ⇔ Cast ∧ distance < R (:226)
+		}
+	}
+	out[idx] = q;
+}
+
+// The colour of an opaque hit (shader.cpp:481-522) and its reflected child (:527-537, :643).
+__global__ void k_shade_post(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits, uint64_t n,
+                             int last, uint32_t branch, uint32_t spp, const uint8_t *__restrict__ shadowed,
+                             const uint8_t *__restrict__ ao_occ, Node *__restrict__ nodes, rtmi_ray *__restrict__ child) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	if (nodes[k].kind != kOpaque) return;
+	const rtmi_ray r = rays[k];
+	const rtmi_hit h = hits[k];
+	const rtmi_material m = S.mats[h.object];
+	const D3 diffuse = ld(m.diffuse), specular = ld(m.specular), ambient = ld(m.ambient), reflective = ld(m.reflectivity);
+	const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
+	const D3 P = hit_point(r, S.v1_orig + 3 * (size_t)h.tri, Ns);
+	const D3 N = unit(Ns);          // :416
+	const D3 E = unit(ld(r.o) - P); // :417
+	D3 color = d3(0, 0, 0);
+	if (shadowed[k]) {
+		color = 0.7 * ambient; // :131-135
+	} else {
+		double occlusion = 1.0;
+		if (ao_occ && spp && nonzero(m.ambient)) {
+			int c = 0;
+			for (uint32_t s = 0; s < spp; ++s) c += ao_occ[k * spp + s];
+			occlusion = (1.0 - (c / (double)spp)); // :231
+		}
+		for (uint32_t i = 0; i < S.n_lights; ++i) { // :485-519
+			const D3 emission = ld(S.lights[i].emission);
+			const D3 L = unit(ld(S.lights[i].center) - P);
+			color = color + cmul(emission, ((.85 * occlusion) * ambient) + (max2(0, dot(N, L)) * diffuse)); // :494
+			if (m.roughness != 0.0) { // :496-508
+				const D3 H = unit(L + E);
+				const double LH = dot(L, H), NH = dot(N, H);
+				const double g = sqrt((30.0 * 3016.0) - 1.0 + (LH * LH));
+				double Fresnel = 0.5 * pow(g - LH, 2.0) / pow(g + LH, 2.0);
+				Fresnel *= pow(LH * (g + LH) - 1.0, 2.0) / pow(LH * (g - LH) + 1.0, 2.0) + 1.0;
+				const double mm = 0.4;
+				double D = 1.0 / (4.0 * mm * mm * pow(NH, 4.0));
+				const double DPow = (pow(NH, 2.0) - 1.0) / ((mm * mm) * pow(NH, 2.0));
+				D = pow(D, DPow);
+				const double G = min3(1.0, (2.0 * NH * NH) / LH, (2.0 * NH * dot(N, L)) / LH);
+				color = color + (((Fresnel * D * G) / (kPiRef * dot(N, E) * dot(N, L))) * (.7 * specular));
+			} else { // :510-518
+				const D3 RR = (-1.0 * L) + ((2.0 * dot(L, N)) * N);
+				color = color + cmul(emission, pow(max2(0.0, dot(E, RR)), m.phong_exp) * specular);
+			}
+		}
+	}
+	Node nd = nodes[k];
+	const D3 R = (-1.0 * E) + ((2.0 * dot(E, Ns)) * Ns); // :532
+	rtmi_ray c0;
+	inactive(c0);
+	if (last) {
+		nd.kind = kFinal;
+		st(nd.c, color + cmul(reflective, termination())); // :643 with scene.cpp:134-137
+	} else if (!nonzero(m.reflectivity)) {
+		nd.kind = kFinal; // colour + 0·Trace(...)
+		st(nd.c, color);
+	} else {
+		nd.kind = kReflect;
+		st(nd.c, color);
+		st(nd.coef, reflective);
+		set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY); // :534-535
+	}
+	nodes[k] = nd;
+	if (!last) {
+		child[k * branch] = c0;
+		if (branch == 2) { rtmi_ray c1; inactive(c1); child[k * branch + 1] = c1; }
+	}
+}
+
+// Returns of Shade, deepest generation first: shader.cpp:614, :640, :643.
+__global__ void k_fold(Node *__restrict__ nodes, const Node *__restrict__ kids, uint64_t n, uint32_t branch) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	const uint32_t kind = nodes[k].kind;
+	if (kind < kReflect) return;
+	const D3 a = ld(kids[k * branch].c), coef = ld(nodes[k].coef);
+	D3 c;
+	if (kind == kReflect) c = ld(nodes[k].c) + cmul(coef, a);
+	else if (kind == kTir) c = cmul(coef, a);
+	else {
+		const double beerR = nodes[k].beer;
+		c = cmul(coef, (beerR * a) + ((1 - beerR) * ld(kids[k * branch + 1].c)));
+	}
+	st(nodes[k].c, c);
+	nodes[k].kind = kFinal;
+}
+
+// ToneMap, rasterizer.cpp:79-88
+__device__ __forceinline__ uint8_t tone(double c) {
+	const int v = (int)floor(256 * c);
+	return (uint8_t)(v >= 255 ? 255 : v);
+}
+__global__ void k_emit(const Node *__restrict__ nodes, const uint64_t *__restrict__ root, uint64_t n, uint64_t sub,
+                       double *__restrict__ rgb, uint8_t *__restrict__ pixels) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	const uint64_t dst = root[k];
+	if (dst == ~0ull) return;
+	const Node nd = nodes[k];
+	const uint64_t at = dst - sub;
+	if (rgb) { rgb[3 * at] = nd.c[0]; rgb[3 * at + 1] = nd.c[1]; rgb[3 * at + 2] = nd.c[2]; }
+	if (pixels) { pixels[3 * at] = tone(nd.c[0]); pixels[3 * at + 1] = tone(nd.c[1]); pixels[3 * at + 2] = tone(nd.c[2]); }
+}
+__global__ void k_fill_colour(uint64_t n, double r, double g, double b, double *__restrict__ rgb) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	rgb[3 * k] = r; rgb[3 * k + 1] = g; rgb[3 * k + 2] = b;
+}
+__global__ void k_tone_map(const double *__restrict__ rgb, uint64_t n3, uint8_t *__restrict__ pixels) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < n3) pixels[k] = tone(rgb[k]);
+}
+
+static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255) / 256)); }
+
+// One chunk of root rays through all generations.  rays(1) and root[] are already filled for `n` slots.
+struct Chunk {
+	uint64_t cap;      // root rays per chunk
+	uint32_t levels, branch, spp;
+	std::vector<uint64_t> slots; // per level, at capacity
+	std::vector<rtmi_ray *> rays;
+	std::vector<Node *> nodes;
+	rtmi_hit *hits;
+	rtmi_ray *shadow, *ao;
+	uint8_t *shadowed, *ao_occ;
+	uint64_t *root;
+};
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Lays the chunk's buffers out in the shader's workspace, growing it if needed.  want = root rays the caller has.
+static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t spp, Chunk &c, const char *who) {
+	c.levels = levels;
+	c.branch = sh->any_translucent ? 2u : 1u;
+	c.spp = (sh->any_ambient ? spp : 0u);
+	// bytes per root ray
+	double per = 8.0, s = 1.0, smax = 1.0;
+	for (uint32_t g = 0; g < levels; ++g) { per += s * (sizeof(rtmi_ray) + sizeof(Node)); smax = s; s *= c.branch; }
+	per += smax * (sizeof(rtmi_hit) + sizeof(rtmi_ray) + 1 + (double)c.spp * (sizeof(rtmi_ray) + 1));
+	const double budget = (double)env_uint("RTMI_SHADE_WS_MB", 4096) * 1048576.0;
+	uint64_t cap = (uint64_t)(budget / per);
+	cap = std::max<uint64_t>(256, cap & ~(uint64_t)255);
+	cap = std::min<uint64_t>(cap, (want + 255) & ~(uint64_t)255);
+	if (smax * (double)cap * std::max(1u, c.spp) > 2.0e9) return fail(std::string(who) + ": ray tree too wide for one launch; lower max_tree_depth");
+	c.cap = cap;
+	c.slots.assign(levels, 0);
+	size_t off = 0;
+	auto take = [&](size_t bytes) { size_t at = off; off += align_up(bytes); return at; };
+	std::vector<size_t> o_rays(levels), o_nodes(levels);
+	uint64_t sl = cap;
+	for (uint32_t g = 0; g < levels; ++g) {
+		c.slots[g] = sl;
+		o_rays[g] = take(sl * sizeof(rtmi_ray));
+		o_nodes[g] = take(sl * sizeof(Node));
+		sl *= c.branch;
+	}
+	const uint64_t mx = c.slots[levels - 1];
+	const size_t o_hits = take(mx * sizeof(rtmi_hit)), o_sh = take(mx * sizeof(rtmi_ray)), o_shb = take(mx);
+	const size_t o_ao = take(c.spp ? mx * c.spp * sizeof(rtmi_ray) : 0), o_aob = take(c.spp ? mx * c.spp : 0);
+	const size_t o_root = take(cap * sizeof(uint64_t));
+	if (off > sh->ws_bytes) {
+		if (sh->ws) { (void)hipDeviceSynchronize(); (void)hipFree(sh->ws); sh->ws = nullptr; sh->ws_bytes = 0; }
+		if (hipMalloc(&sh->ws, off) != hipSuccess) return fail(std::string(who) + ": hipMalloc of the workspace failed");
+		sh->ws_bytes = off;
+	}
+	c.rays.resize(levels); c.nodes.resize(levels);
+	for (uint32_t g = 0; g < levels; ++g) { c.rays[g] = (rtmi_ray *)(sh->ws + o_rays[g]); c.nodes[g] = (Node *)(sh->ws + o_nodes[g]); }
+	c.hits = (rtmi_hit *)(sh->ws + o_hits);
+	c.shadow = (rtmi_ray *)(sh->ws + o_sh);
+	c.shadowed = (uint8_t *)(sh->ws + o_shb);
+	c.ao = (rtmi_ray *)(sh->ws + o_ao);
+	c.ao_occ = (uint8_t *)(sh->ws + o_aob);
+	c.root = (uint64_t *)(sh->ws + o_root);
+	return 0;
+}
+
+// generations first_gen .. first_gen+levels-1 of n root rays; c.rays[0][0..n) and c.root[0..n) are filled.
+static int run_chunk(rtmi_shader *sh, const Chunk &c, uint64_t n, const rtmi_trace_params &p, hipStream_t st, const char *who) {
+	const ShadeDev S = {sh->scene->d_v1_orig, sh->d_normals, sh->d_mats, sh->d_lights, sh->n_lights};
+	uint64_t slots = n, path0 = 1;
+	uint32_t per_root = 1;
+	for (uint32_t g = 0; g < c.levels; ++g) {
+		const int last = (g + 1 == c.levels);
+		rtmi_ray *child = last ? nullptr : c.rays[g + 1];
+		if (rtmi_closest_hit_dev(sh->scene, c.rays[g], slots, c.hits, st)) return -1;
+		hipLaunchKernelGGL(k_shade_pre, grid_for(slots), dim3(256), 0, st, S, c.rays[g], c.hits, slots, last, c.branch, c.nodes[g], c.shadow, child);
+		if (rtmi_any_hit_dev(sh->scene, c.shadow, slots, c.shadowed, st)) return -1;
+		const uint8_t *ao_occ = nullptr;
+		if (c.spp) {
+			hipLaunchKernelGGL(k_node_ao_rays, grid_for(slots * c.spp), dim3(256), 0, st, S, c.rays[g], c.hits, c.nodes[g], c.shadowed, c.root, slots,
+			                   per_root, path0, c.spp, p.ao_radius, p.seed, c.ao);
+			if (rtmi_any_hit_dev(sh->scene, c.ao, slots * c.spp, c.ao_occ, st)) return -1;
+			ao_occ = c.ao_occ;
+		}
+		hipLaunchKernelGGL(k_shade_post, grid_for(slots), dim3(256), 0, st, S, c.rays[g], c.hits, slots, last, c.branch, c.spp, c.shadowed, ao_occ,
+		                   c.nodes[g], child);
+		slots *= c.branch;
+		per_root *= c.branch;
+		path0 *= 2;
+	}
+	for (int g = (int)c.levels - 2; g >= 0; --g) {
+		uint64_t sl = n;
+		for (int q = 0; q < g; ++q) sl *= c.branch;
+		hipLaunchKernelGGL(k_fold, grid_for(sl), dim3(256), 0, st, c.nodes[g], c.nodes[g + 1], sl, c.branch);
+	}
+	return launch_check(who);
+}
+
+static int check_params(const rtmi_trace_params *p, const char *who) {
+	if (!p) return fail(std::string(who) + ": params is NULL");
+	if (p->ao_rays && !(p->ao_radius > 0.0)) return fail(std::string(who) + ": ao_radius must be positive");
+	if (p->max_tree_depth > 16) return fail(std::string(who) + ": max_tree_depth > 16");
+	return 0;
+}
+
+} // namespace rtmi
+
+using namespace rtmi;
+
+extern "C" {
+
+rtmi_shader *rtmi_shader_create(rtmi_scene *s, const double *tri_normals, const rtmi_material *mats, uint32_t n_objects,
+                                const rtmi_light *lights, uint32_t n_lights) {
+	const char *who = "rtmi_shader_create";
+	if (check_scene(s, who)) return nullptr;
+	if (!tri_normals || !mats || !lights) { fail(std::string(who) + ": NULL argument"); return nullptr; }
+	if (n_lights == 0) { fail(std::string(who) + ": the shader needs at least one light (shader.cpp:120 reads light 0)"); return nullptr; }
+	if (n_objects < s->n_objects) { fail(std::string(who) + ": fewer materials than the scene has objects"); return nullptr; }
+	rtmi_shader *sh = new rtmi_shader();
+	sh->scene = s; sh->n_objects = n_objects; sh->n_lights = n_lights;
+	sh->d_normals = nullptr; sh->d_mats = nullptr; sh->d_lights = nullptr; sh->ws = nullptr; sh->ws_bytes = 0;
+	sh->any_translucent = sh->any_ambient = false;
+	for (uint32_t k = 0; k < n_objects; ++k) {
+		const rtmi_material &m = mats[k];
+		if (m.translucency[0] > 0.0 && m.translucency[1] > 0.0 && m.translucency[2] > 0.0) sh->any_translucent = true;
+		if (m.ambient[0] != 0.0 || m.ambient[1] != 0.0 || m.ambient[2] != 0.0) sh->any_ambient = true;
+	}
+	const size_t nb = std::max<size_t>(1, s->n_tris) * 3 * sizeof(double);
+	bool ok = hipMalloc(&sh->d_normals, nb) == hipSuccess && hipMalloc(&sh->d_mats, n_objects * sizeof(rtmi_material)) == hipSuccess &&
+	          hipMalloc(&sh->d_lights, n_lights * sizeof(rtmi_light)) == hipSuccess;
+	if (ok && s->n_tris) ok = hipMemcpy(sh->d_normals, tri_normals, s->n_tris * 3 * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && hipMemcpy(sh->d_mats, mats, n_objects * sizeof(rtmi_material), hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && hipMemcpy(sh->d_lights, lights, n_lights * sizeof(rtmi_light), hipMemcpyHostToDevice) == hipSuccess;
+	if (!ok) {
+		rtmi_shader_destroy(sh);
+		fail(std::string(who) + ": allocation or upload failed");
+		return nullptr;
+	}
+	return sh;
+}
+
+void rtmi_shader_destroy(rtmi_shader *sh) {
+	if (!sh) return;
+	if (sh->d_normals) (void)hipFree(sh->d_normals);
+	if (sh->d_mats) (void)hipFree(sh->d_mats);
+	if (sh->d_lights) (void)hipFree(sh->d_lights);
+	if (sh->ws) (void)hipFree(sh->ws);
+	delete sh;
+}
+
+int rtmi_trace_dev(rtmi_shader *sh, const rtmi_ray *d_rays, uint64_t n, uint32_t generation, uint64_t first_index,
+                   const rtmi_trace_params *params, double *d_rgb, void *stream) {
+	const char *who = "rtmi_trace_dev";
+	if (!sh) return fail(std::string(who) + ": shader is NULL");
+	if (check_scene(sh->scene, who) || check_params(params, who)) return -1;
+	if (n == 0) return 0;
+	if (!d_rays || !d_rgb) return fail(std::string(who) + ": NULL argument");
+	hipStream_t st = (hipStream_t)stream;
+	if (generation > params->max_tree_depth) { // scene.cpp:134-137
+		hipLaunchKernelGGL(k_fill_colour, grid_for(n), dim3(256), 0, st, n, 0.0, 0.0, 0.0, d_rgb);
+		return launch_check(who);
+	}
+	Chunk c;
+	if (plan_chunk(sh, n, params->max_tree_depth - generation + 1, params->ao_rays, c, who)) return -1;
+	for (uint64_t at = 0; at < n; at += c.cap) {
+		const uint64_t m = std::min<uint64_t>(c.cap, n - at);
+		if (hipMemcpyAsync(c.rays[0], d_rays + at, m * sizeof(rtmi_ray), hipMemcpyDeviceToDevice, st) != hipSuccess)
+			return fail(std::string(who) + ": copy of the rays failed");
+		hipLaunchKernelGGL(k_batch_roots, grid_for(m), dim3(256), 0, st, first_index + at, m, c.root);
+		if (run_chunk(sh, c, m, *params, st, who)) return -1;
+		hipLaunchKernelGGL(k_emit, grid_for(m), dim3(256), 0, st, c.nodes[0], c.root, m, first_index, d_rgb, (uint8_t *)nullptr);
+	}
+	return launch_check(who);
+}
+
+int rtmi_render_frame_dev(rtmi_shader *sh, const rtmi_camera *cam, double sx, double sy, uint32_t tile_w, uint32_t tile_h,
+                          uint32_t tile_first, uint32_t tile_stride, const rtmi_trace_params *params, double *d_rgb,
+                          uint8_t *d_pixels, void *stream) {
+	const char *who = "rtmi_render_frame_dev";
+	if (!sh) return fail(std::string(who) + ": shader is NULL");
+	if (check_scene(sh->scene, who) || check_params(params, who)) return -1;
+	if (!cam || (!d_rgb && !d_pixels)) return fail(std::string(who) + ": NULL argument");
+	if (cam->x_res == 0 || cam->y_res == 0) return 0;
+	if (tile_w == 0 || tile_h == 0) { tile_w = cam->x_res; tile_h = cam->y_res; }
+	if (tile_stride == 0) return fail(std::string(who) + ": tile_stride must be >= 1");
+	if ((uint64_t)tile_w * tile_h > 0x7fffffffull) return fail(std::string(who) + ": tile too large");
+	const uint32_t tiles_x = (cam->x_res + tile_w - 1) / tile_w, tiles_y = (cam->y_res + tile_h - 1) / tile_h;
+	const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
+	if (tile_first >= n_tiles) return 0;
+	const uint64_t mine = (n_tiles - tile_first + tile_stride - 1) / tile_stride;
+	const uint64_t n = mine * tile_w * tile_h;
+	hipStream_t st = (hipStream_t)stream;
+	if (params->max_tree_depth == 0) return fail(std::string(who) + ": max_tree_depth must be >= 1 (primary rays are generation 1)");
+	const FrameGrid g = {tile_w, tile_h, tiles_x, tile_first, tile_stride};
+	Chunk c;
+	if (plan_chunk(sh, n, params->max_tree_depth, params->ao_rays, c, who)) return -1;
+	for (uint64_t at = 0; at < n; at += c.cap) {
+		const uint64_t m = std::min<uint64_t>(c.cap, n - at);
+		hipLaunchKernelGGL(k_frame_rays, grid_for(m), dim3(256), 0, st, *cam, sx, sy, g, at, m, c.rays[0], c.root);
+		if (run_chunk(sh, c, m, *params, st, who)) return -1;
+		hipLaunchKernelGGL(k_emit, grid_for(m), dim3(256), 0, st, c.nodes[0], c.root, m, (uint64_t)0, d_rgb, d_pixels);
+	}
+	return launch_check(who);
+}
+
+int rtmi_tone_map_dev(const double *d_rgb, uint64_t n, uint8_t *d_pixels, void *stream) {
+	const char *who = "rtmi_tone_map_dev";
+	if (n == 0) return 0;
+	if (!d_rgb || !d_pixels) return fail(std::string(who) + ": NULL argument");
+	hipLaunchKernelGGL(k_tone_map, grid_for(3 * n), dim3(256), 0, (hipStream_t)stream, d_rgb, 3 * n, d_pixels);
+	return launch_check(who);
+}
+
+} // extern "C"

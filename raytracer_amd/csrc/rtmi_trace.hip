@@ -200,6 +200,8 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 
 	rtmi_scene *s = new rtmi_scene();
 	s->n_tris = n;
+	s->n_objects = 1;
+	if (obj) for (uint64_t i = 0; i < n; ++i) s->n_objects = std::max(s->n_objects, obj[i] + 1u);
 	s->info.n_tris = n;
 	s->info.n_leaves = bvh.n_leaves;
 	s->info.max_depth = bvh.depth;

@@ -6,31 +6,6 @@
 
 namespace rtmi {
 
-constexpr double kPiRef = 3.14159265358979; // Render2/base.h:52
-
-__device__ __forceinline__ D3 cross(D3 a, D3 b) { // vec3.h:50
-	return d3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-__device__ __forceinline__ uint64_t wf_mix64(uint64_t z) {
-	z += 0x9E3779B97F4A7C15ull;
-	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-	return z ^ (z >> 31);
-}
-
-// hit.point of updateHitInfo (object.cpp:23): origin + (direction·((triVert1 − origin)·n)) / (n·direction)
-__device__ __forceinline__ D3 hit_point(const rtmi_ray &r, const double *v1, D3 n) {
-	const D3 o = d3(r.o[0], r.o[1], r.o[2]), d = d3(r.d[0], r.d[1], r.d[2]);
-	return o + (dot(d3(v1[0], v1[1], v1[2]) - o, n) * d) / dot(n, d);
-}
-
-__device__ __forceinline__ void inactive(rtmi_ray &q) {
-	q.o[0] = q.o[1] = q.o[2] = 0.0;
-	q.d[0] = q.d[1] = 0.0; q.d[2] = 1.0;
-	q.tmax = RTMI_INFINITY;
-	q.reserved = 1.0;
-}
-
 // generateNormalShadows (shader.cpp:116-127): origin P + 0.01·normal, direction Unit(C − P)
 __global__ void k_shadow_rays(const double *__restrict__ v1_orig, const double *__restrict__ normals,
                               const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits, uint64_t n, double cx,
@@ -70,33 +45,9 @@ __global__ void k_ao_rays(const double *__restrict__ v1_orig, const double *__re
 	} else {
 		const D3 nrm = d3(normals[3 * (size_t)h.tri], normals[3 * (size_t)h.tri + 1], normals[3 * (size_t)h.tri + 2]);
 		const D3 P = hit_point(rays[k], v1_orig + 3 * (size_t)h.tri, nrm);
-		const D3 Z = unit(nrm); // :153
-		D3 t = Z;
-		const double cz = fabs(Z.z), cx = fabs(Z.x), cy = fabs(Z.y);
-		if (cz <= cx) { // :160-168, the reference's own branch structure
-			if (cz <= cy) t.z = 1;
-		} else if (cx <= cz) {
-			if (cx <= cy) t.x = 1;
-		} else t.y = 1;
-		const D3 X = unit(cross(t, Z)); // :170
-		const D3 Y = cross(Z, X);       // :171
 		const uint64_t hsh = wf_mix64(wf_mix64(seed ^ k) ^ (uint64_t)s);
-		const double a = (2.0 * ((double)(hsh >> 11) * 0x1.0p-53)) - 1.0; // dis(gen) − 1, dis = uniform(0, 2)
-		const double b = (2.0 * ((double)(wf_mix64(hsh) >> 11) * 0x1.0p-53)) - 1.0;
-		double phi, r;
-		if (a > -b) { // :182-204
-			if (a > b) { r = a; phi = (kPiRef / 4.0) * (b / a); }
-			else { r = b; phi = (kPiRef / 4.0) * (2.0 - (a / b)); }
-		} else {
-			if (a < b) { r = -a; phi = (kPiRef / 4.0) * (4.0 + (b / a)); }
-			else { r = -b; phi = (b != 0) ? (kPiRef / 4.0) * (6.0 - (a / b)) : 0; }
-		}
-		const double u = r * cos(phi), v = r * sin(phi);               // :206-207
-		const D3 base = (u * X) + (v * Y);                             // :210-211
-		const double lb = sqrt(len2(base));
-		const double leg = (R * R) - (lb * lb);                        // :212
-		const D3 dir = unit(((leg / R) * Z) + base);                   // :214,218
-		const D3 org = P + (.0001 * dir);                              // :220
+		D3 org, dir;
+		ao_ray(P, nrm, R, hsh, org, dir);
 		q.o[0] = org.x; q.o[1] = org.y; q.o[2] = org.z;
 		q.d[0] = dir.x; q.d[1] = dir.y; q.d[2] = dir.z;
 		q.tmax = R; // occluded ⇔ Cast ∧ distance < R (:226)

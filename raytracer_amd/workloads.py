@@ -62,6 +62,76 @@ def closed_box(k, side=10.0, hole=0.0):
     return verts, normals, light
 
 
+def _quad(p0, p1, p3, k):
+    """k x k quads spanned by p0->p1 and p0->p3, two triangles each; normal = (p1-p0) x (p3-p0) direction."""
+    p0, p1, p3 = (np.asarray(x, np.float64) for x in (p0, p1, p3))
+    e1, e2 = (p1 - p0) / k, (p3 - p0) / k
+    out = []
+    for a in range(k):
+        for b in range(k):
+            q = p0 + a * e1 + b * e2
+            out.append(np.concatenate([q, q + e1, q + e1 + e2]))
+            out.append(np.concatenate([q, q + e1 + e2, q + e2]))
+    return np.array(out)
+
+
+def _box(lo, hi, k=1):
+    """axis-aligned box, outward faces"""
+    (x0, y0, z0), (x1, y1, z1) = lo, hi
+    f = [((x0, y0, z0), (x0, y1, z0), (x1, y0, z0)),  # bottom (-z)
+         ((x0, y0, z1), (x1, y0, z1), (x0, y1, z1)),  # top (+z)
+         ((x0, y0, z0), (x1, y0, z0), (x0, y0, z1)),  # -y
+         ((x0, y1, z0), (x0, y1, z1), (x1, y1, z0)),  # +y
+         ((x0, y0, z0), (x0, y0, z1), (x0, y1, z0)),  # -x
+         ((x1, y0, z0), (x1, y1, z0), (x1, y0, z1))]  # +x
+    return np.concatenate([_quad(a, b, c, k) for a, b, c in f])
+
+
+def face_normals(verts):
+    """Unit((v2 - v1) x (v3 - v2)), the reference's normal for faces without vertex normals (params.cpp:199-208)"""
+    v = np.asarray(verts, np.float64).reshape(-1, 3, 3)
+    n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 1])
+    return n / np.sqrt((n * n).sum(1))[:, None]
+
+
+# material rows: diffuse, specular, ambient, reflectivity, translucency (3 each), Phong_exp, ref_index, roughness
+def material(diffuse=(0, 0, 0), specular=(0, 0, 0), ambient=(0, 0, 0), reflectivity=(0, 0, 0), translucency=(0, 0, 0),
+             phong_exp=0.0, ref_index=0.0, roughness=0.0):
+    return np.array(list(diffuse) + list(specular) + list(ambient) + list(reflectivity) + list(translucency) +
+                    [phong_exp, ref_index, roughness], np.float64)
+
+
+STUDIO_CAM14 = np.array([10.0, -9.0, 8.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, 2.75, -1.25, 1.25, -1.0, 1.0])
+
+
+def studio(k=2, ambient=0.0):
+    """An open scene that exercises every branch of Shader::Shade (shader.cpp:395-645): a diffuse floor, a mirror-like
+    back wall, a Phong box, a microfacet box and a refracting sheet, lit by two lights from above (the reference calls a
+    point shadowed when ANYTHING lies along the ray to light 0, shader.cpp:131, so the scene has no ceiling).
+    Returns (verts n x 9, object id per triangle, materials n_obj x 18, lights n_l x 6)."""
+    parts = [
+        (_quad((-8, -8, 0), (8, -8, 0), (-8, 8, 0), 2 * k), material(diffuse=(0.84, 0.37, 0.38), ambient=(ambient,) * 3,
+                                                                    reflectivity=(0.1, 0.1, 0.1), phong_exp=2.0)),
+        (_quad((-8, 8, 0), (8, 8, 0), (-8, 8, 6), k), material(diffuse=(0.1, 0.1, 0.12), specular=(0.3, 0.3, 0.3),
+                                                              ambient=(ambient,) * 3, reflectivity=(0.6, 0.6, 0.55),
+                                                              phong_exp=20.0)),
+        (_box((-4, -1, 0), (-1.5, 1.5, 2.5), k), material(diffuse=(0.2, 0.5, 0.8), specular=(0.5, 0.5, 0.5),
+                                                          ambient=(ambient,) * 3, phong_exp=8.0)),
+        (_box((1.0, 1.0, 0), (3.5, 3.5, 1.5), k), material(diffuse=(0.6, 0.6, 0.2), specular=(0.4, 0.35, 0.3),
+                                                          ambient=(ambient,) * 3, reflectivity=(0.05, 0.05, 0.05),
+                                                          roughness=0.4)),
+        (_quad((1.0, -4.0, 0.2), (4.5, -2.5, 0.2), (1.0, -4.0, 3.2), k), material(translucency=(0.2, 0.3, 0.4),
+                                                                                 ref_index=1.5)),
+        (_box((-1.0, -5.5, 0), (0.5, -4.0, 1.5), 1), material(diffuse=(0.3, 0.3, 0.3), translucency=(0.15, 0.1, 0.05),
+                                                            ref_index=1.33)),
+    ]
+    verts = np.concatenate([p for p, _ in parts])
+    obj = np.concatenate([np.full(len(p), i, np.uint32) for i, (p, _) in enumerate(parts)])
+    mats = np.stack([m for _, m in parts])
+    lights = np.array([[3.0, -2.0, 12.0, 1.0, 1.0, 1.0], [-6.0, -8.0, 9.0, 0.3, 0.2, 0.1]])
+    return verts, obj, mats, lights
+
+
 def synthetic_F(n, n_rows=None, row0=0, seed=1, row_sum=0.9, device="cuda", ld=None):
     """C5 solver-only matrix, generated on the device in row blocks: entries uniform(0,1), zero diagonal,
     every row rescaled to sum `row_sum`.  Rows [row0, row0+n_rows) of the n x n matrix (fp32, ld >= n)."""

@@ -1,0 +1,132 @@
+"""Scene::Trace + Shader::Shade on the device (rtmi_trace_dev / rtmi_render_frame_dev) against the oracle's
+restatement (same seeded AO stream: hit ids, shadow and occlusion bits identical; colours within TOL because pow / exp /
+sin / cos come from the device library) and against the compiled reference's own colours (tests/golden/g6_*)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, frame_rays, ao_steps
+
+pytestmark = pytest.mark.gpu
+
+# floating point: the device's pow/exp/sin/cos differ from glibc's by a few ulp; colours are O(1)
+TOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    import raytracer_amd
+    return raytracer_amd
+
+
+def _shader(rt, g, mats="mats", **kw):
+    scene = rt.Scene(g["tris"], g["tri_obj"])
+    return scene, rt.Shader(scene, g["normals"], g[mats], g["lights"], **kw)
+
+
+@pytest.mark.parametrize("depth", [1, 3])
+def test_studio_vs_reference_golden(rt, oracle, depth):
+    """ambient 0: the compiled reference's colours are reproducible; every branch of Shade is on the frame"""
+    g = load_golden("g6_shade_studio.npz")
+    scene, sh = _shader(rt, g, max_tree_depth=depth, ao_rays=10)
+    cam = rt.Camera.from_cam14(g["cam14"], g["res"])
+    rgb, pix = sh.Rasterize(cam)
+    ref = g["rgb_d%d" % depth].reshape(rgb.shape)
+    assert np.abs(rgb - ref).max() < TOL
+    if depth == 1:
+        # ToneMap bytes: identical except where 256·c sits within TOL of an integer
+        diff = (pix != g["pixels_d1"].reshape(pix.shape))
+        edge = np.abs(256 * ref - np.round(256 * ref)) < 256 * TOL
+        assert not (diff & ~edge).any()
+
+
+def test_studio_ambient_same_stream_as_oracle(rt, oracle):
+    """ambient 0.1, 10 AO rays, depth 3: same seeded stream as the oracle -> same occlusion counts -> colours within TOL;
+    also in two halves of the tiles (multi-GPU sharding) and through rtmi_trace_dev on a ray batch"""
+    g = load_golden("g6_shade_studio.npz")
+    o, d, _ = frame_rays(oracle, g["cam14"], g["res"])
+    want = oracle.trace(g["tris"], g["normals"], g["tri_obj"], g["mats_amb"], g["lights"], o, d, max_depth=3, ao_rays=10, seed=5)
+    scene, sh = _shader(rt, g, "mats_amb", max_tree_depth=3, ao_rays=10, seed=5)
+    cam = rt.Camera.from_cam14(g["cam14"], g["res"])
+    rgb, _ = sh.Rasterize(cam)
+    assert np.abs(rgb.reshape(-1, 3) - want).max() < TOL
+    # tiles 32 x 24, rank 0 of 2 and rank 1 of 2: the union is the frame, each pixel written once
+    a, _ = sh.Rasterize(cam, tile=(32, 24), tile_first=0, tile_stride=2)
+    b, _ = sh.Rasterize(cam, tile=(32, 24), tile_first=1, tile_stride=2)
+    assert np.array_equal(np.where(a != 0, a, b), rgb) and not ((a != 0) & (b != 0)).any()
+    # ragged tiles (not multiples of 8, not dividing the frame)
+    c, _ = sh.Rasterize(cam, tile=(50, 37))
+    assert np.array_equal(c, rgb)
+    # the same rays as a batch, in two calls with first_index
+    rays = rt.make_rays(o, d)
+    h = len(rays) // 3
+    got = np.concatenate([sh.Trace(rays[:h]), sh.Trace(rays[h:], first_index=h)])
+    assert np.array_equal(got, rgb.reshape(-1, 3))
+    # the reference's colours: same up to its own random occlusion count (integer steps)
+    occ1 = oracle.trace(g["tris"], g["normals"], g["tri_obj"], g["mats_amb"], g["lights"], o, d, max_depth=1, ao_rays=0)
+    sh1 = rt.Shader(scene, g["normals"], g["mats_amb"], g["lights"], max_tree_depth=1, ao_rays=10, seed=9)
+    mine, _ = sh1.Rasterize(cam)
+    k_ref = 10 * ao_steps(g["rgb_amb"], occ1, g["tris"], g["tri_obj"], g["mats_amb"], g["lights"], oracle, o, d)
+    k_gpu = 10 * ao_steps(mine.reshape(-1, 3), occ1, g["tris"], g["tri_obj"], g["mats_amb"], g["lights"], oracle, o, d)
+    lit = ~np.isnan(k_ref[:, 0]) & (np.abs(occ1 - 0.07).max(1) > 1e-12)
+    assert np.abs(k_gpu[lit] - np.round(k_gpu[lit])).max() < 1e-6
+    assert abs(k_gpu[lit, 0].mean() - k_ref[lit, 0].mean()) < 0.1
+
+
+def test_generation_beyond_depth_and_small_workspace(rt, oracle, monkeypatch):
+    g = load_golden("g6_shade_studio.npz")
+    o, d, _ = frame_rays(oracle, g["cam14"], g["res"])
+    scene, sh = _shader(rt, g, max_tree_depth=2, ao_rays=0)
+    rays = rt.make_rays(o[:1000], d[:1000])
+    assert np.array_equal(sh.Trace(rays, generation=3), np.zeros((1000, 3)))     # scene.cpp:134-137: termination colour
+    want = oracle.trace(g["tris"], g["normals"], g["tri_obj"], g["mats"], g["lights"], o[:1000], d[:1000], max_depth=2, ao_rays=0,
+                        generation=2)
+    assert np.abs(sh.Trace(rays, generation=2) - want).max() < TOL
+    # a 1 MiB workspace forces many chunks; the frame must not change
+    cam = rt.Camera.from_cam14(g["cam14"], g["res"])
+    full, _ = sh.Rasterize(cam)
+    monkeypatch.setenv("RTMI_SHADE_WS_MB", "1")
+    scene2, sh2 = _shader(rt, g, max_tree_depth=2, ao_rays=0)
+    small, _ = sh2.Rasterize(cam)
+    assert np.array_equal(full, small)
+
+
+def test_test1_frame_as_shipped(rt, oracle):
+    """scenes/test1 at the reference's settings (500 x 400, ambient 0.1, 10 AO rays, depth 1)"""
+    g = load_golden("g6_shade_test1.npz")
+    scene, sh = _shader(rt, g, max_tree_depth=1, ao_rays=10, seed=1)
+    cam = rt.Camera.from_cam14(g["cam14"], g["res"])
+    rgb, pix = sh.Rasterize(cam)
+    rgb = rgb.reshape(-1, 3)
+    o, d, _ = frame_rays(oracle, g["cam14"], g["res"])
+    want = oracle.trace(g["tris"], g["normals"], g["tri_obj"], g["mats"], g["lights"], o, d, max_depth=1, ao_rays=10, seed=1)
+    assert np.abs(rgb - want).max() < TOL
+    wp = oracle.tone_map(want)
+    edge = (np.abs(256 * want - np.round(256 * want)) < 256 * TOL)
+    assert not ((pix.reshape(-1, 3) != wp) & ~edge).any()
+    # against the reference's own frame: equal where AO cannot act, integer occlusion steps elsewhere
+    sub = g["sub"]
+    occ1 = oracle.trace(g["tris"], g["normals"], g["tri_obj"], g["mats"], g["lights"], o[sub], d[sub], max_depth=1, ao_rays=0)
+    k_ref = 10 * ao_steps(g["rgb_sub"], occ1, g["tris"], g["tri_obj"], g["mats"], g["lights"], oracle, o[sub], d[sub])
+    k_gpu = 10 * ao_steps(rgb[sub], occ1, g["tris"], g["tri_obj"], g["mats"], g["lights"], oracle, o[sub], d[sub])
+    flat = np.isnan(k_ref[:, 0])
+    assert np.abs(rgb[sub][flat] - g["rgb_sub"][flat]).max() < 1e-9
+    lit = ~flat & (np.abs(occ1 - 0.07).max(1) > 1e-12)
+    assert abs(k_gpu[lit, 0].mean() - k_ref[lit, 0].mean()) < 0.1
+    # the image as a whole: the reference's ToneMap bytes differ from ours only through those occlusion steps
+    dpx = np.abs(pix.reshape(-1, 3).astype(int) - g["pixels"].astype(int))
+    assert dpx.max() <= int(256 * 0.85 * 0.1) + 1
+
+
+def test_shader_errors(rt):
+    g = load_golden("g6_shade_studio.npz")
+    scene = rt.Scene(g["tris"], g["tri_obj"])
+    with pytest.raises(rt.RtmiError, match="light"):
+        rt.Shader(scene, g["normals"], g["mats"], np.zeros((0, 6)))
+    with pytest.raises(rt.RtmiError, match="materials"):
+        rt.Shader(scene, g["normals"], g["mats"][:3], g["lights"])
+    sh = rt.Shader(scene, g["normals"], g["mats"], g["lights"], ao_rays=10, ao_radius=0.0)
+    with pytest.raises(rt.RtmiError, match="ao_radius"):
+        sh.Rasterize(rt.Camera.from_cam14(g["cam14"], g["res"]))

@@ -179,3 +179,63 @@ def test_g3_ao_construction_statistics(oracle):
     assert np.allclose(np.linalg.norm(d2, axis=1), 1.0, atol=1e-15)
     assert np.allclose(o2 - g["P"][:1], 1e-4 * d2, atol=1e-18)
     assert np.all(d2 @ g["N"][0] > 0)                                 # rays leave into the hemisphere of the normal
+
+
+# ---- G6: Scene::Trace / Shader::Shade -------------------------------------------------------------------
+def test_g6_shade_studio_bit_exact(oracle):
+    """Every material's ambient is 0, so the reference's unseeded AO draw cannot reach the colour: the restatement must
+    equal the compiled reference's Scene::Trace to the bit at max_tree_depth 1 and 3 (Phong, microfacet, mirror,
+    refraction in and out, total internal reflection, background)."""
+    from conftest import frame_rays
+    g = load_golden("g6_shade_studio.npz")
+    o, d, _ = frame_rays(oracle, g["cam14"], g["res"])
+    for depth in (1, 3):
+        mine = oracle.trace(g["tris"], g["normals"], g["tri_obj"], g["mats"], g["lights"], o, d, max_depth=depth, ao_rays=10)
+        assert np.array_equal(mine, g["rgb_d%d" % depth])
+    assert np.array_equal(oracle.tone_map(g["rgb_d1"]), g["pixels_d1"])
+    # the fixture does exercise the branches
+    obj_hit = g["tri_obj"][np.maximum(oracle.closest_hit(g["tris"], o, d)[0], 0)]
+    assert set(np.unique(obj_hit)) == set(range(6))
+    assert (g["rgb_d3"] != g["rgb_d1"]).any(1).mean() > 0.3
+
+
+def test_g6_shade_ambient_steps(oracle):
+    """ambient 0.1: reference colour = colour(occlusion 1) − (k/10)·0.85·ambient·Σemission with an integer k in 0..10,
+    the same on the three channels; shadowed pixels and misses are equal outright."""
+    from conftest import frame_rays, ao_steps
+    g = load_golden("g6_shade_studio.npz")
+    o, d, _ = frame_rays(oracle, g["cam14"], g["res"])
+    occ1 = oracle.trace(g["tris"], g["normals"], g["tri_obj"], g["mats_amb"], g["lights"], o, d, max_depth=1, ao_rays=0)
+    k = 10 * ao_steps(g["rgb_amb"], occ1, g["tris"], g["tri_obj"], g["mats_amb"], g["lights"], oracle, o, d)
+    lit = ~np.isnan(k[:, 0]) & (np.abs(occ1 - g["rgb_amb"]).max(1) > 0)
+    assert lit.sum() > 1000
+    kk = k[lit]
+    assert np.abs(kk - np.round(kk)).max() < 1e-9
+    assert kk.min() > -0.5 and kk.max() < 10.5
+    assert (np.round(kk) == np.round(kk[:, :1])).all()
+    same = np.isnan(k[:, 0])
+    assert np.array_equal(occ1[same], g["rgb_amb"][same])
+    # and the restatement's own seeded AO has the same mean occlusion as the reference's draw
+    mine = oracle.trace(g["tris"], g["normals"], g["tri_obj"], g["mats_amb"], g["lights"], o, d, max_depth=1, ao_rays=10, seed=3)
+    km = 10 * ao_steps(mine, occ1, g["tris"], g["tri_obj"], g["mats_amb"], g["lights"], oracle, o, d)
+    unshadowed = ~np.isnan(k[:, 0]) & (np.abs(occ1 - 0.7 * 0.1).max(1) > 1e-12)   # shadowed = 0.7·ambient (shader.cpp:135)
+    assert unshadowed.sum() > 2000
+    assert abs(km[unshadowed, 0].mean() - k[unshadowed, 0].mean()) < 0.1
+
+
+def test_g6_shade_test1_as_shipped(oracle):
+    """scenes/test1 as main.cpp renders it (the reference's own BSP, ambient 0.1, 10 AO rays, depth 1)."""
+    from conftest import frame_rays, ao_steps
+    g = load_golden("g6_shade_test1.npz")
+    o, d, _ = frame_rays(oracle, g["cam14"], g["res"])
+    sub = g["sub"]
+    o, d = o[sub], d[sub]
+    occ1 = oracle.trace(g["tris"], g["normals"], g["tri_obj"], g["mats"], g["lights"], o, d, max_depth=1, ao_rays=0)
+    k = 10 * ao_steps(g["rgb_sub"], occ1, g["tris"], g["tri_obj"], g["mats"], g["lights"], oracle, o, d)
+    lit = ~np.isnan(k[:, 0])
+    # hit points come from the BSP's fragments there (1e-12 away from ours): steps are integers to 1e-6, not 1e-9
+    kk = k[lit]
+    assert np.abs(kk - np.round(kk)).max() < 1e-6
+    assert kk.min() > -0.5 and kk.max() < 10.5
+    assert np.abs(occ1[~lit] - g["rgb_sub"][~lit]).max() < 1e-9
+    assert np.array_equal(oracle.tone_map(g["rgb_sub"]), g["pixels"][sub])
