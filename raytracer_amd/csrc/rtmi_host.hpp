@@ -27,4 +27,9 @@ int launch_check(const char *who);
 int check_scene(const rtmi_scene *s, const char *who); // NULL / wrong current device -> -1
 unsigned env_uint(const char *name, unsigned dflt); // tuning overrides from the environment
 Tune refill_threshold();                          // RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF       // hipGetLastError() after a launch -> 0 / -1
+// ray queries whose ray count lives on the device: min(cap, *d_n · mul) rays of the buffer are traced
+int closest_hit_counted(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t cap, const uint32_t *d_n, uint32_t mul, rtmi_hit *d_out,
+                        void *stream, const char *who);
+int any_hit_counted(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t cap, const uint32_t *d_n, uint32_t mul, uint8_t *d_occ,
+                    void *stream, const char *who);
 } // namespace rtmi

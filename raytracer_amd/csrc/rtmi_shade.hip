@@ -7,11 +7,13 @@
 // few ulp, not to the bit (hit ids, shadow and occlusion bits are exact).  gfx950 only.
 //
 // The reference recurses per pixel; here one generation of the ray tree is one batch:
-//   closest hit -> k_shade_pre (hit point, shadow ray, refraction children) -> any hit (shadow)
+//   closest hit -> k_shade_pre (hit point, shadow ray, refraction children) -> any hit (shadow) -> k_ao_list
 //   -> k_node_ao_rays -> any hit (AO) -> k_shade_post (colour, reflection child) -> next generation ... -> k_fold
-// Slot s of generation g has its children at slots branch·s (+1) of generation g+1; branch = 2 if any material
-// refracts, else 1.  Work the reference does but whose result it never uses is skipped: AO where the point is shadowed
-// or the material's ambient is 0, local colour of refracting materials, a reflected ray whose weight is 0.
+// Generations are COMPACT: a node reserves slots for its children from a device-side counter (one atomic per wave),
+// AO rays exist only for the nodes that will use the answer, and every launch reads its item count on the device, so a
+// frame is queued without the host ever waiting.  Work the reference does but whose result it never uses is skipped:
+// AO where the point is shadowed or the material's ambient is 0, the local colour of refracting materials, a reflected
+// ray whose weight is 0.
 #include <vector>
 
 #include "rtmi_host.hpp"
@@ -37,11 +39,17 @@ struct ShadeDev {
 };
 
 enum : uint32_t { kDead = 0, kFinal = 1, kOpaque = 2, kReflect = 3, kRefract = 4, kTir = 5 };
-struct Node { // 64 bytes per slot
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+struct Node { // 80 bytes per slot
 	double c[3];    // colour (local until folded, then final)
 	double coef[3]; // reflectivity (kReflect) or translucency weights (kRefract, kTir)
 	double beer;    // Schlick weight of the reflected child (kRefract)
-	uint32_t kind, pad;
+	uint32_t kind;
+	uint32_t child;    // first child's slot in the next generation (kReflect, kTir: 1 child; kRefract: 2)
+	uint32_t rootslot; // slot of the generation-1 ray this node descends from -> root[] = its ray index
+	uint32_t path;     // 1 = that ray itself, 2p = reflected child of p, 2p+1 = refracted child of p
+	uint32_t ao_at;    // position in the AO list, kNone if no AO ray is shot for this node
+	uint32_t pad;
 };
 
 constexpr double kEpsilon = 1.0e-5; // Render2/base.h:57
@@ -61,8 +69,29 @@ __device__ __forceinline__ bool refracts(const rtmi_material &m) { // shader.cpp
 }
 __device__ __forceinline__ bool nonzero(const double *c) { return c[0] != 0.0 || c[1] != 0.0 || c[2] != 0.0; }
 
+// Every lane of the wave calls this (converged code) with the number of slots it needs (0, 1 or 2); returns the lane's
+// first slot.  One atomic per wave.
+__device__ __forceinline__ uint32_t reserve(uint32_t *counter, uint32_t need) {
+	const unsigned long long b1 = __ballot(need >= 1), b2 = __ballot(need >= 2);
+	const uint32_t total = (uint32_t)(__popcll(b1) + __popcll(b2));
+	if (total == 0) return 0;
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t base = 0;
+	if (lane == 0) base = atomicAdd(counter, total);
+	base = __shfl(base, 0, 64);
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	return base + (uint32_t)(__popcll(b1 & lt) + __popcll(b2 & lt));
+}
+
+// Elementwise kernels run a fixed grid and stride over the items; the item count is read on the device.  A wave handles
+// 64 consecutive items per step so that reserve() sees whole waves.
+#define RTMI_FOR_ITEMS(k, in, count)                                                                              \
+	for (uint64_t k##_b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ull, k = k##_b + (threadIdx.x & 63u); \
+	     k##_b < (count); k##_b += (uint64_t)gridDim.x * blockDim.x, k += (uint64_t)gridDim.x * blockDim.x)         \
+		if (const bool in = k < (count); true)
+
 // Generation-1 rays of a frame, rasterizer.cpp:230.  Items enumerate this rank's tiles (tile_first, + tile_stride, ...),
-// 8×8-pixel squares inside a tile when its sides allow; items that fall outside the frame are inactive slots.
+// 8×8-pixel squares inside a tile when its sides allow; items that fall outside the frame are dead slots.
 struct FrameGrid { uint32_t tile_w, tile_h, tiles_x, tile_first, tile_stride; };
 __device__ __forceinline__ bool frame_pixel(const FrameGrid &g, const rtmi_camera &cam, uint64_t item, uint32_t &i, uint32_t &j) {
 	const uint32_t per_tile = g.tile_w * g.tile_h;
@@ -80,223 +109,267 @@ __device__ __forceinline__ bool frame_pixel(const FrameGrid &g, const rtmi_camer
 	i = (tile / g.tiles_x) * g.tile_h + ly;
 	return j < cam.x_res && i < cam.y_res;
 }
+// counts[0] = n, every other counter = 0
+__global__ void k_set_counts(uint32_t *counts, uint32_t n_counters, uint32_t n) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < n_counters) counts[k] = k == 0 ? n : 0u;
+}
 __global__ void k_frame_rays(rtmi_camera cam, double sx, double sy, FrameGrid g, uint64_t item0, uint64_t n,
                              rtmi_ray *__restrict__ rays, uint64_t *__restrict__ root) {
-	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= n) return;
-	uint32_t i, j;
-	rtmi_ray R;
-	if (frame_pixel(g, cam, item0 + k, i, j)) {
-		const D3 O = ld(cam.O), dR = ld(cam.dR), dU = ld(cam.dU);
-		set_ray(R, ld(cam.eye), unit((O + (j + sx) * dR) - (i + sy) * dU), RTMI_INFINITY);
-		root[k] = (uint64_t)i * cam.x_res + j;
-	} else {
-		inactive(R);
-		root[k] = ~0ull;
+	RTMI_FOR_ITEMS(k, in, n) {
+		if (!in) continue;
+		uint32_t i, j;
+		rtmi_ray R;
+		if (frame_pixel(g, cam, item0 + k, i, j)) {
+			const D3 O = ld(cam.O), dR = ld(cam.dR), dU = ld(cam.dU);
+			set_ray(R, ld(cam.eye), unit((O + (j + sx) * dR) - (i + sy) * dU), RTMI_INFINITY);
+			root[k] = (uint64_t)i * cam.x_res + j;
+		} else {
+			inactive(R);
+			root[k] = ~0ull;
+		}
+		rays[k] = R;
 	}
-	rays[k] = R;
 }
 __global__ void k_batch_roots(uint64_t first, uint64_t n, uint64_t *__restrict__ root) {
-	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (k < n) root[k] = first + k;
+	RTMI_FOR_ITEMS(k, in, n) {
+		if (in) root[k] = first + k;
+	}
 }
 
 // Everything of Shade that needs no secondary-ray answer: classify the slot, refraction (shader.cpp:542-641), the
 // shadow ray (:116-127).  `last`: the children would be generation max_tree_depth+1, for which Trace returns the
 // termination colour without casting (scene.cpp:134-137), so they are folded in at once.
-__global__ void k_shade_pre(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits, uint64_t n,
-                            int last, uint32_t branch, Node *__restrict__ nodes, rtmi_ray *__restrict__ shadow,
-                            rtmi_ray *__restrict__ child) {
-	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= n) return;
-	Node nd;
-	nd.c[0] = nd.c[1] = nd.c[2] = 0.0; nd.coef[0] = nd.coef[1] = nd.coef[2] = 0.0; nd.beer = 0.0; nd.kind = kDead; nd.pad = 0;
-	rtmi_ray sh, c0, c1;
-	inactive(sh); inactive(c0); inactive(c1);
-	bool write_children = !last;
-	const rtmi_ray r = rays[k];
-	if (r.reserved == 0.0) {
-		const rtmi_hit h = hits[k];
-		if (h.tri == RTMI_MISS) {
-			nd.kind = kFinal;
-			st(nd.c, background()); // scene.cpp:151
-		} else {
-			const rtmi_material m = S.mats[h.object];
-			const D3 Ns = ld(S.normals + 3 * (size_t)h.tri); // hit.normal = triNormal, object.cpp:17
-			const D3 P = hit_point(r, S.v1_orig + 3 * (size_t)h.tri, Ns);
-			if (refracts(m)) {
-				const double kk = m.ref_index;
-				const D3 E = unit(ld(r.o) - P); // :417
-				D3 transl = ld(m.translucency);
-				const D3 mE = -1.0 * E, mN = -1.0 * Ns;
-				D3 R, tRefr = d3(0, 0, 0);
-				double refractionCoef = 0;
-				bool tir = false;
-				if (dot(E, Ns) < 0.0) R = (-1.0 * E) + ((2.0 * dot(E, mN)) * mN); // :571-574
-				else R = (-1.0 * E) + ((2.0 * dot(E, Ns)) * Ns);
-				if (dot(mE, Ns) < 0.0) { // :576-588
-					const double dn = dot(mE, Ns);
-					const D3 cosRefract = (mE - (dn * Ns)) / kk;
-					const double cosSq = 1 - ((1 - (dn * dn)) / (kk * kk));
-					tRefr = cosRefract - (sqrt(cosSq) * Ns);
-					refractionCoef = dot(E, Ns);
-					transl = d3(1, 1, 1);
-				} else { // :589-625
-					transl = d3(exp(-1.0 * transl.x * h.t), exp(-1.0 * transl.y * h.t), exp(-1.0 * transl.z * h.t));
-					const double dn = dot(mE, mN);
-					const D3 cosRefract = (mE - (dn * mN)) / kk;
-					const double cosSq = 1 - ((1 - (dn * dn)) / (kk * kk));
-					if (cosSq < 0.0) tir = true; // :608-615
-					else {
-						tRefr = cosRefract - (sqrt(cosSq) * mN);
-						refractionCoef = dot(tRefr, Ns);
-					}
-				}
-				st(nd.coef, transl);
-				if (tir) {
-					if (last) { nd.kind = kFinal; st(nd.c, cmul(transl, termination())); }
-					else { nd.kind = kTir; set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY); }
+__global__ void k_shade_pre(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
+                            const uint32_t *__restrict__ d_count, int first, int last, Node *__restrict__ nodes,
+                            rtmi_ray *__restrict__ shadow, uint32_t *__restrict__ kid_count, rtmi_ray *__restrict__ kid_rays,
+                            Node *__restrict__ kid_nodes) {
+	const uint64_t count = *d_count;
+	RTMI_FOR_ITEMS(k, in, count) {
+		Node nd;
+		nd.c[0] = nd.c[1] = nd.c[2] = 0.0; nd.coef[0] = nd.coef[1] = nd.coef[2] = 0.0; nd.beer = 0.0;
+		nd.kind = kDead; nd.child = kNone; nd.ao_at = kNone; nd.pad = 0;
+		nd.rootslot = first ? (uint32_t)k : (in ? nodes[k].rootslot : 0u);
+		nd.path = first ? 1u : (in ? nodes[k].path : 0u);
+		rtmi_ray sh, c0, c1;
+		inactive(sh);
+		uint32_t need = 0;
+		if (in) {
+			const rtmi_ray r = rays[k];
+			if (r.reserved == 0.0) {
+				const rtmi_hit h = hits[k];
+				if (h.tri == RTMI_MISS) {
+					nd.kind = kFinal;
+					st(nd.c, background()); // scene.cpp:151
 				} else {
-					const double beerR0 = ((1 - kk) * (1 - kk)) / ((1 + kk) * (1 + kk));         // :627
-					const double beerR = beerR0 + (1 - beerR0) * pow(1 - refractionCoef, 5.0); // :628
-					nd.beer = beerR;
-					if (last) {
-						nd.kind = kFinal;
-						st(nd.c, cmul(transl, (beerR * termination()) + ((1 - beerR) * termination()))); // :640
+					const rtmi_material m = S.mats[h.object];
+					const D3 Ns = ld(S.normals + 3 * (size_t)h.tri); // hit.normal = triNormal, object.cpp:17
+					const D3 P = hit_point(r, S.v1_orig + 3 * (size_t)h.tri, Ns);
+					if (refracts(m)) {
+						const double kk = m.ref_index;
+						const D3 E = unit(ld(r.o) - P); // :417
+						D3 transl = ld(m.translucency);
+						const D3 mE = -1.0 * E, mN = -1.0 * Ns;
+						D3 R, tRefr = d3(0, 0, 0);
+						double refractionCoef = 0;
+						bool tir = false;
+						if (dot(E, Ns) < 0.0) R = (-1.0 * E) + ((2.0 * dot(E, mN)) * mN); // :571-574
+						else R = (-1.0 * E) + ((2.0 * dot(E, Ns)) * Ns);
+						if (dot(mE, Ns) < 0.0) { // :576-588
+							const double dn = dot(mE, Ns);
+							const D3 cosRefract = (mE - (dn * Ns)) / kk;
+							const double cosSq = 1 - ((1 - (dn * dn)) / (kk * kk));
+							tRefr = cosRefract - (sqrt(cosSq) * Ns);
+							refractionCoef = dot(E, Ns);
+							transl = d3(1, 1, 1);
+						} else { // :589-625
+							transl = d3(exp(-1.0 * transl.x * h.t), exp(-1.0 * transl.y * h.t), exp(-1.0 * transl.z * h.t));
+							const double dn = dot(mE, mN);
+							const D3 cosRefract = (mE - (dn * mN)) / kk;
+							const double cosSq = 1 - ((1 - (dn * dn)) / (kk * kk));
+							if (cosSq < 0.0) tir = true; // :608-615
+							else {
+								tRefr = cosRefract - (sqrt(cosSq) * mN);
+								refractionCoef = dot(tRefr, Ns);
+							}
+						}
+						st(nd.coef, transl);
+						if (tir) {
+							if (last) { nd.kind = kFinal; st(nd.c, cmul(transl, termination())); }
+							else { nd.kind = kTir; need = 1; set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY); }
+						} else {
+							const double beerR0 = ((1 - kk) * (1 - kk)) / ((1 + kk) * (1 + kk));         // :627
+							const double beerR = beerR0 + (1 - beerR0) * pow(1 - refractionCoef, 5.0); // :628
+							nd.beer = beerR;
+							if (last) {
+								nd.kind = kFinal;
+								st(nd.c, cmul(transl, (beerR * termination()) + ((1 - beerR) * termination()))); // :640
+							} else {
+								nd.kind = kRefract;
+								need = 2;
+								set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY);         // :630-633
+								set_ray(c1, P + (kEpsilon * tRefr), tRefr, RTMI_INFINITY); // :635-638
+							}
+						}
 					} else {
-						nd.kind = kRefract;
-						set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY);         // :630-633
-						set_ray(c1, P + (kEpsilon * tRefr), tRefr, RTMI_INFINITY); // :635-638
+						nd.kind = kOpaque; // colour and reflection: k_shade_post
+						set_ray(sh, P + (0.01 * Ns), unit(ld(S.lights[0].center) - P), RTMI_INFINITY); // :122,127
 					}
 				}
-			} else {
-				nd.kind = kOpaque; // colour and reflection: k_shade_post
-				write_children = false;
-				set_ray(sh, P + (0.01 * Ns), unit(ld(S.lights[0].center) - P), RTMI_INFINITY); // :122,127
 			}
 		}
-	}
-	nodes[k] = nd;
-	shadow[k] = sh;
-	if (write_children) {
-		child[k * branch] = c0;
-		if (branch == 2) child[k * branch + 1] = c1;
+		const uint32_t at = reserve(kid_count, need);
+		if (need) {
+			nd.child = at;
+			kid_rays[at] = c0;
+			kid_nodes[at].rootslot = nd.rootslot; kid_nodes[at].path = 2u * nd.path;
+			if (need == 2) {
+				kid_rays[at + 1] = c1;
+				kid_nodes[at + 1].rootslot = nd.rootslot; kid_nodes[at + 1].path = 2u * nd.path + 1u;
+			}
+		}
+		if (in) {
+			nodes[k] = nd;
+			shadow[k] = sh;
+		}
 	}
 }
 
-// findOcclusionNew's rays (shader.cpp:140-232) for the slots that will use the answer.  Square points: stream
-// (mix64(seed ^ path), root ray index, sample); path = 1 for the traced ray itself, 2p / 2p+1 for the children of p.
-__global__ void k_node_ao_rays(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
-                               const Node *__restrict__ nodes, const uint8_t *__restrict__ shadowed,
-                               const uint64_t *__restrict__ root, uint64_t n, uint32_t per_root, uint64_t path0, uint32_t spp,
-                               double R, uint64_t seed, rtmi_ray *__restrict__ out) {
-	const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= n * spp) return;
-	const uint64_t k = idx / spp;
-	const uint32_t s = (uint32_t)(idx % spp);
-	rtmi_ray q;
-	inactive(q);
-	if (nodes[k].kind == kOpaque && !shadowed[k]) {
-		const rtmi_hit h = hits[k];
-		if (nonzero(S.mats[h.object].ambient)) {
-			const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
-			const D3 P = hit_point(rays[k], S.v1_orig + 3 * (size_t)h.tri, Ns);
-			const uint64_t path = path0 + (per_root > 1 ? k % per_root : 0);
-			const uint64_t hsh = wf_mix64(wf_mix64(wf_mix64(seed ^ path) ^ root[k / per_root]) ^ (uint64_t)s);
-			D3 org, dir;
-			ao_ray(P, Ns, R, hsh, org, dir);
-			set_ray(q, org, dir, R); // occluded ⇔ Cast ∧ distance < R (:226)
+// The nodes whose AO answer will be used: opaque, not shadowed, ambient != 0.
+__global__ void k_ao_list(ShadeDev S, const rtmi_hit *__restrict__ hits, const uint32_t *__restrict__ d_count,
+                          const uint8_t *__restrict__ shadowed, Node *__restrict__ nodes, uint32_t *__restrict__ ao_count,
+                          uint32_t *__restrict__ ao_slot) {
+	const uint64_t count = *d_count;
+	RTMI_FOR_ITEMS(k, in, count) {
+		const uint32_t need = (in && nodes[k].kind == kOpaque && !shadowed[k] && nonzero(S.mats[hits[k].object].ambient)) ? 1u : 0u;
+		const uint32_t at = reserve(ao_count, need);
+		if (need) {
+			nodes[k].ao_at = at;
+			ao_slot[at] = (uint32_t)k;
 		}
 	}
-	out[idx] = q;
+}
+
+// findOcclusionNew's rays (shader.cpp:140-232), spp per listed node.  Square points: stream
+// (mix64(seed ^ path), root ray index, sample).
+__global__ void k_node_ao_rays(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
+                               const Node *__restrict__ nodes, const uint32_t *__restrict__ ao_slot,
+                               const uint32_t *__restrict__ ao_count, const uint64_t *__restrict__ root, uint32_t spp, double R,
+                               uint64_t seed, rtmi_ray *__restrict__ out) {
+	const uint64_t count = (uint64_t)*ao_count * spp;
+	RTMI_FOR_ITEMS(idx, in, count) {
+		if (!in) continue;
+		const uint32_t at = (uint32_t)(idx / spp), s = (uint32_t)(idx - (uint64_t)at * spp);
+		const uint32_t k = ao_slot[at];
+		const rtmi_hit h = hits[k];
+		const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
+		const D3 P = hit_point(rays[k], S.v1_orig + 3 * (size_t)h.tri, Ns);
+		const uint64_t hsh = wf_mix64(wf_mix64(wf_mix64(seed ^ (uint64_t)nodes[k].path) ^ root[nodes[k].rootslot]) ^ (uint64_t)s);
+		D3 org, dir;
+		ao_ray(P, Ns, R, hsh, org, dir);
+		rtmi_ray q;
+		set_ray(q, org, dir, R); // occluded ⇔ Cast ∧ distance < R (:226)
+		out[idx] = q;
+	}
 }
 
 // The colour of an opaque hit (shader.cpp:481-522) and its reflected child (:527-537, :643).
-__global__ void k_shade_post(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits, uint64_t n,
-                             int last, uint32_t branch, uint32_t spp, const uint8_t *__restrict__ shadowed,
-                             const uint8_t *__restrict__ ao_occ, Node *__restrict__ nodes, rtmi_ray *__restrict__ child) {
-	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= n) return;
-	if (nodes[k].kind != kOpaque) return;
-	const rtmi_ray r = rays[k];
-	const rtmi_hit h = hits[k];
-	const rtmi_material m = S.mats[h.object];
-	const D3 diffuse = ld(m.diffuse), specular = ld(m.specular), ambient = ld(m.ambient), reflective = ld(m.reflectivity);
-	const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
-	const D3 P = hit_point(r, S.v1_orig + 3 * (size_t)h.tri, Ns);
-	const D3 N = unit(Ns);          // :416
-	const D3 E = unit(ld(r.o) - P); // :417
-	D3 color = d3(0, 0, 0);
-	if (shadowed[k]) {
-		color = 0.7 * ambient; // :131-135
-	} else {
-		double occlusion = 1.0;
-		if (ao_occ && spp && nonzero(m.ambient)) {
-			int c = 0;
-			for (uint32_t s = 0; s < spp; ++s) c += ao_occ[k * spp + s];
-			occlusion = (1.0 - (c / (double)spp)); // :231
-		}
-		for (uint32_t i = 0; i < S.n_lights; ++i) { // :485-519
-			const D3 emission = ld(S.lights[i].emission);
-			const D3 L = unit(ld(S.lights[i].center) - P);
-			color = color + cmul(emission, ((.85 * occlusion) * ambient) + (max2(0, dot(N, L)) * diffuse)); // :494
-			if (m.roughness != 0.0) { // :496-508
-				const D3 H = unit(L + E);
-				const double LH = dot(L, H), NH = dot(N, H);
-				const double g = sqrt((30.0 * 3016.0) - 1.0 + (LH * LH));
-				double Fresnel = 0.5 * pow(g - LH, 2.0) / pow(g + LH, 2.0);
-				Fresnel *= pow(LH * (g + LH) - 1.0, 2.0) / pow(LH * (g - LH) + 1.0, 2.0) + 1.0;
-				const double mm = 0.4;
-				double D = 1.0 / (4.0 * mm * mm * pow(NH, 4.0));
-				const double DPow = (pow(NH, 2.0) - 1.0) / ((mm * mm) * pow(NH, 2.0));
-				D = pow(D, DPow);
-				const double G = min3(1.0, (2.0 * NH * NH) / LH, (2.0 * NH * dot(N, L)) / LH);
-				color = color + (((Fresnel * D * G) / (kPiRef * dot(N, E) * dot(N, L))) * (.7 * specular));
-			} else { // :510-518
-				const D3 RR = (-1.0 * L) + ((2.0 * dot(L, N)) * N);
-				color = color + cmul(emission, pow(max2(0.0, dot(E, RR)), m.phong_exp) * specular);
+__global__ void k_shade_post(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
+                             const uint32_t *__restrict__ d_count, int last, uint32_t spp, const uint8_t *__restrict__ shadowed,
+                             const uint8_t *__restrict__ ao_occ, Node *__restrict__ nodes, uint32_t *__restrict__ kid_count,
+                             rtmi_ray *__restrict__ kid_rays, Node *__restrict__ kid_nodes) {
+	const uint64_t count = *d_count;
+	RTMI_FOR_ITEMS(k, in, count) {
+		uint32_t need = 0;
+		rtmi_ray c0;
+		Node nd;
+		const bool mine = in && nodes[k].kind == kOpaque;
+		if (mine) {
+			nd = nodes[k];
+			const rtmi_ray r = rays[k];
+			const rtmi_hit h = hits[k];
+			const rtmi_material m = S.mats[h.object];
+			const D3 diffuse = ld(m.diffuse), specular = ld(m.specular), ambient = ld(m.ambient), reflective = ld(m.reflectivity);
+			const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
+			const D3 P = hit_point(r, S.v1_orig + 3 * (size_t)h.tri, Ns);
+			const D3 N = unit(Ns);          // :416
+			const D3 E = unit(ld(r.o) - P); // :417
+			D3 color = d3(0, 0, 0);
+			if (shadowed[k]) {
+				color = 0.7 * ambient; // :131-135
+			} else {
+				double occlusion = 1.0;
+				if (nd.ao_at != kNone) {
+					int c = 0;
+					for (uint32_t s = 0; s < spp; ++s) c += ao_occ[(uint64_t)nd.ao_at * spp + s];
+					occlusion = (1.0 - (c / (double)spp)); // :231
+				}
+				for (uint32_t i = 0; i < S.n_lights; ++i) { // :485-519
+					const D3 emission = ld(S.lights[i].emission);
+					const D3 L = unit(ld(S.lights[i].center) - P);
+					color = color + cmul(emission, ((.85 * occlusion) * ambient) + (max2(0, dot(N, L)) * diffuse)); // :494
+					if (m.roughness != 0.0) { // :496-508
+						const D3 H = unit(L + E);
+						const double LH = dot(L, H), NH = dot(N, H);
+						const double g = sqrt((30.0 * 3016.0) - 1.0 + (LH * LH));
+						double Fresnel = 0.5 * pow(g - LH, 2.0) / pow(g + LH, 2.0);
+						Fresnel *= pow(LH * (g + LH) - 1.0, 2.0) / pow(LH * (g - LH) + 1.0, 2.0) + 1.0;
+						const double mm = 0.4;
+						double D = 1.0 / (4.0 * mm * mm * pow(NH, 4.0));
+						const double DPow = (pow(NH, 2.0) - 1.0) / ((mm * mm) * pow(NH, 2.0));
+						D = pow(D, DPow);
+						const double G = min3(1.0, (2.0 * NH * NH) / LH, (2.0 * NH * dot(N, L)) / LH);
+						color = color + (((Fresnel * D * G) / (kPiRef * dot(N, E) * dot(N, L))) * (.7 * specular));
+					} else { // :510-518
+						const D3 RR = (-1.0 * L) + ((2.0 * dot(L, N)) * N);
+						color = color + cmul(emission, pow(max2(0.0, dot(E, RR)), m.phong_exp) * specular);
+					}
+				}
+			}
+			const D3 R = (-1.0 * E) + ((2.0 * dot(E, Ns)) * Ns); // :532
+			if (last) {
+				nd.kind = kFinal;
+				st(nd.c, color + cmul(reflective, termination())); // :643 with scene.cpp:134-137
+			} else if (!nonzero(m.reflectivity)) {
+				nd.kind = kFinal; // colour + 0·Trace(...)
+				st(nd.c, color);
+			} else {
+				nd.kind = kReflect;
+				need = 1;
+				st(nd.c, color);
+				st(nd.coef, reflective);
+				set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY); // :534-535
 			}
 		}
-	}
-	Node nd = nodes[k];
-	const D3 R = (-1.0 * E) + ((2.0 * dot(E, Ns)) * Ns); // :532
-	rtmi_ray c0;
-	inactive(c0);
-	if (last) {
-		nd.kind = kFinal;
-		st(nd.c, color + cmul(reflective, termination())); // :643 with scene.cpp:134-137
-	} else if (!nonzero(m.reflectivity)) {
-		nd.kind = kFinal; // colour + 0·Trace(...)
-		st(nd.c, color);
-	} else {
-		nd.kind = kReflect;
-		st(nd.c, color);
-		st(nd.coef, reflective);
-		set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY); // :534-535
-	}
-	nodes[k] = nd;
-	if (!last) {
-		child[k * branch] = c0;
-		if (branch == 2) { rtmi_ray c1; inactive(c1); child[k * branch + 1] = c1; }
+		const uint32_t at = reserve(kid_count, need);
+		if (need) {
+			nd.child = at;
+			kid_rays[at] = c0;
+			kid_nodes[at].rootslot = nd.rootslot; kid_nodes[at].path = 2u * nd.path;
+		}
+		if (mine) nodes[k] = nd;
 	}
 }
 
 // Returns of Shade, deepest generation first: shader.cpp:614, :640, :643.
-__global__ void k_fold(Node *__restrict__ nodes, const Node *__restrict__ kids, uint64_t n, uint32_t branch) {
-	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= n) return;
-	const uint32_t kind = nodes[k].kind;
-	if (kind < kReflect) return;
-	const D3 a = ld(kids[k * branch].c), coef = ld(nodes[k].coef);
-	D3 c;
-	if (kind == kReflect) c = ld(nodes[k].c) + cmul(coef, a);
-	else if (kind == kTir) c = cmul(coef, a);
-	else {
-		const double beerR = nodes[k].beer;
-		c = cmul(coef, (beerR * a) + ((1 - beerR) * ld(kids[k * branch + 1].c)));
+__global__ void k_fold(Node *__restrict__ nodes, const Node *__restrict__ kids, const uint32_t *__restrict__ d_count) {
+	const uint64_t count = *d_count;
+	RTMI_FOR_ITEMS(k, in, count) {
+		if (!in) continue;
+		const uint32_t kind = nodes[k].kind;
+		if (kind < kReflect) continue;
+		const uint32_t at = nodes[k].child;
+		const D3 a = ld(kids[at].c), coef = ld(nodes[k].coef);
+		D3 c;
+		if (kind == kReflect) c = ld(nodes[k].c) + cmul(coef, a);
+		else if (kind == kTir) c = cmul(coef, a);
+		else {
+			const double beerR = nodes[k].beer;
+			c = cmul(coef, (beerR * a) + ((1 - beerR) * ld(kids[at + 1].c)));
+		}
+		st(nodes[k].c, c);
+		nodes[k].kind = kFinal;
 	}
-	st(nodes[k].c, c);
-	nodes[k].kind = kFinal;
 }
 
 // ToneMap, rasterizer.cpp:79-88
@@ -306,56 +379,65 @@ __device__ __forceinline__ uint8_t tone(double c) {
 }
 __global__ void k_emit(const Node *__restrict__ nodes, const uint64_t *__restrict__ root, uint64_t n, uint64_t sub,
                        double *__restrict__ rgb, uint8_t *__restrict__ pixels) {
-	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= n) return;
-	const uint64_t dst = root[k];
-	if (dst == ~0ull) return;
-	const Node nd = nodes[k];
-	const uint64_t at = dst - sub;
-	if (rgb) { rgb[3 * at] = nd.c[0]; rgb[3 * at + 1] = nd.c[1]; rgb[3 * at + 2] = nd.c[2]; }
-	if (pixels) { pixels[3 * at] = tone(nd.c[0]); pixels[3 * at + 1] = tone(nd.c[1]); pixels[3 * at + 2] = tone(nd.c[2]); }
+	RTMI_FOR_ITEMS(k, in, n) {
+		if (!in) continue;
+		const uint64_t dst = root[k];
+		if (dst == ~0ull || nodes[k].kind == kDead) continue;
+		const uint64_t at = dst - sub;
+		const double r = nodes[k].c[0], g = nodes[k].c[1], b = nodes[k].c[2];
+		if (rgb) { rgb[3 * at] = r; rgb[3 * at + 1] = g; rgb[3 * at + 2] = b; }
+		if (pixels) { pixels[3 * at] = tone(r); pixels[3 * at + 1] = tone(g); pixels[3 * at + 2] = tone(b); }
+	}
 }
 __global__ void k_fill_colour(uint64_t n, double r, double g, double b, double *__restrict__ rgb) {
-	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= n) return;
-	rgb[3 * k] = r; rgb[3 * k + 1] = g; rgb[3 * k + 2] = b;
+	RTMI_FOR_ITEMS(k, in, n) {
+		if (in) { rgb[3 * k] = r; rgb[3 * k + 1] = g; rgb[3 * k + 2] = b; }
+	}
 }
 __global__ void k_tone_map(const double *__restrict__ rgb, uint64_t n3, uint8_t *__restrict__ pixels) {
-	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (k < n3) pixels[k] = tone(rgb[k]);
+	RTMI_FOR_ITEMS(k, in, n3) {
+		if (in) pixels[k] = tone(rgb[k]);
+	}
 }
 
-static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255) / 256)); }
+// fixed grid for the striding elementwise kernels: enough waves to fill the device, never more than the items need
+static inline dim3 grid_for(const rtmi_shader *sh, uint64_t cap) {
+	const uint64_t full = (uint64_t)sh->scene->n_cus * 8u;
+	return dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full, (cap + 255) / 256)));
+}
 
-// One chunk of root rays through all generations.  rays(1) and root[] are already filled for `n` slots.
+// One chunk of generation-1 rays through all generations.
 struct Chunk {
-	uint64_t cap;      // root rays per chunk
+	uint64_t cap; // generation-1 rays per chunk
 	uint32_t levels, branch, spp;
-	std::vector<uint64_t> slots; // per level, at capacity
+	std::vector<uint64_t> slots; // capacity per generation
 	std::vector<rtmi_ray *> rays;
 	std::vector<Node *> nodes;
 	rtmi_hit *hits;
 	rtmi_ray *shadow, *ao;
 	uint8_t *shadowed, *ao_occ;
+	uint32_t *ao_slot;
 	uint64_t *root;
+	uint32_t *counts; // [0, levels]: nodes per generation (one spare), [levels+1, 2·levels]: AO-list length per generation
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// Lays the chunk's buffers out in the shader's workspace, growing it if needed.  want = root rays the caller has.
+// Lays the chunk's buffers out in the shader's workspace, growing it if needed.  want = generation-1 rays the caller has.
 static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t spp, Chunk &c, const char *who) {
 	c.levels = levels;
 	c.branch = sh->any_translucent ? 2u : 1u;
 	c.spp = (sh->any_ambient ? spp : 0u);
-	// bytes per root ray
+	// bytes per generation-1 ray at capacity
 	double per = 8.0, s = 1.0, smax = 1.0;
 	for (uint32_t g = 0; g < levels; ++g) { per += s * (sizeof(rtmi_ray) + sizeof(Node)); smax = s; s *= c.branch; }
-	per += smax * (sizeof(rtmi_hit) + sizeof(rtmi_ray) + 1 + (double)c.spp * (sizeof(rtmi_ray) + 1));
-	const double budget = (double)env_uint("RTMI_SHADE_WS_MB", 4096) * 1048576.0;
+	per += smax * (sizeof(rtmi_hit) + sizeof(rtmi_ray) + 1 + 4 + (double)c.spp * (sizeof(rtmi_ray) + 1));
+	const double budget = (double)env_uint("RTMI_SHADE_WS_MB", 8192) * 1048576.0;
 	uint64_t cap = (uint64_t)(budget / per);
 	cap = std::max<uint64_t>(256, cap & ~(uint64_t)255);
 	cap = std::min<uint64_t>(cap, (want + 255) & ~(uint64_t)255);
-	if (smax * (double)cap * std::max(1u, c.spp) > 2.0e9) return fail(std::string(who) + ": ray tree too wide for one launch; lower max_tree_depth");
+	if (smax * (double)cap * std::max(1u, c.spp) > 4.0e9) cap = std::max<uint64_t>(256, (uint64_t)(4.0e9 / (smax * std::max(1u, c.spp))) & ~(uint64_t)255);
+	if (smax * (double)cap * std::max(1u, c.spp) > 4.0e9) return fail(std::string(who) + ": ray tree too wide for one launch; lower max_tree_depth");
 	c.cap = cap;
 	c.slots.assign(levels, 0);
 	size_t off = 0;
@@ -371,7 +453,9 @@ static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t 
 	const uint64_t mx = c.slots[levels - 1];
 	const size_t o_hits = take(mx * sizeof(rtmi_hit)), o_sh = take(mx * sizeof(rtmi_ray)), o_shb = take(mx);
 	const size_t o_ao = take(c.spp ? mx * c.spp * sizeof(rtmi_ray) : 0), o_aob = take(c.spp ? mx * c.spp : 0);
+	const size_t o_aos = take(c.spp ? mx * sizeof(uint32_t) : 0);
 	const size_t o_root = take(cap * sizeof(uint64_t));
+	const size_t o_counts = take((2 * levels + 2) * sizeof(uint32_t));
 	if (off > sh->ws_bytes) {
 		if (sh->ws) { (void)hipDeviceSynchronize(); (void)hipFree(sh->ws); sh->ws = nullptr; sh->ws_bytes = 0; }
 		if (hipMalloc(&sh->ws, off) != hipSuccess) return fail(std::string(who) + ": hipMalloc of the workspace failed");
@@ -384,38 +468,41 @@ static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t 
 	c.shadowed = (uint8_t *)(sh->ws + o_shb);
 	c.ao = (rtmi_ray *)(sh->ws + o_ao);
 	c.ao_occ = (uint8_t *)(sh->ws + o_aob);
+	c.ao_slot = (uint32_t *)(sh->ws + o_aos);
 	c.root = (uint64_t *)(sh->ws + o_root);
+	c.counts = (uint32_t *)(sh->ws + o_counts);
 	return 0;
 }
 
-// generations first_gen .. first_gen+levels-1 of n root rays; c.rays[0][0..n) and c.root[0..n) are filled.
+// all generations of n generation-1 rays; c.rays[0][0..n) and c.root[0..n) are filled.
 static int run_chunk(rtmi_shader *sh, const Chunk &c, uint64_t n, const rtmi_trace_params &p, hipStream_t st, const char *who) {
 	const ShadeDev S = {sh->scene->d_v1_orig, sh->d_normals, sh->d_mats, sh->d_lights, sh->n_lights};
-	uint64_t slots = n, path0 = 1;
-	uint32_t per_root = 1;
+	const uint32_t n_counters = 2 * c.levels + 2;
+	hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(64), 0, st, c.counts, n_counters, (uint32_t)n);
+	uint64_t cap = n; // generation capacity for THIS chunk's n (<= c.slots[g])
 	for (uint32_t g = 0; g < c.levels; ++g) {
 		const int last = (g + 1 == c.levels);
-		rtmi_ray *child = last ? nullptr : c.rays[g + 1];
-		if (rtmi_closest_hit_dev(sh->scene, c.rays[g], slots, c.hits, st)) return -1;
-		hipLaunchKernelGGL(k_shade_pre, grid_for(slots), dim3(256), 0, st, S, c.rays[g], c.hits, slots, last, c.branch, c.nodes[g], c.shadow, child);
-		if (rtmi_any_hit_dev(sh->scene, c.shadow, slots, c.shadowed, st)) return -1;
-		const uint8_t *ao_occ = nullptr;
+		uint32_t *cnt = c.counts + g, *kid_cnt = c.counts + g + 1, *ao_cnt = c.counts + c.levels + 1 + g;
+		rtmi_ray *kid_rays = last ? nullptr : c.rays[g + 1];
+		Node *kid_nodes = last ? nullptr : c.nodes[g + 1];
+		if (closest_hit_counted(sh->scene, c.rays[g], cap, cnt, 1, c.hits, st, who)) return -1;
+		hipLaunchKernelGGL(k_shade_pre, grid_for(sh, cap), dim3(256), 0, st, S, c.rays[g], c.hits, cnt, g == 0 ? 1 : 0, last, c.nodes[g],
+		                   c.shadow, kid_cnt, kid_rays, kid_nodes);
+		if (any_hit_counted(sh->scene, c.shadow, cap, cnt, 1, c.shadowed, st, who)) return -1;
 		if (c.spp) {
-			hipLaunchKernelGGL(k_node_ao_rays, grid_for(slots * c.spp), dim3(256), 0, st, S, c.rays[g], c.hits, c.nodes[g], c.shadowed, c.root, slots,
-			                   per_root, path0, c.spp, p.ao_radius, p.seed, c.ao);
-			if (rtmi_any_hit_dev(sh->scene, c.ao, slots * c.spp, c.ao_occ, st)) return -1;
-			ao_occ = c.ao_occ;
+			hipLaunchKernelGGL(k_ao_list, grid_for(sh, cap), dim3(256), 0, st, S, c.hits, cnt, c.shadowed, c.nodes[g], ao_cnt, c.ao_slot);
+			hipLaunchKernelGGL(k_node_ao_rays, grid_for(sh, cap * c.spp), dim3(256), 0, st, S, c.rays[g], c.hits, c.nodes[g], c.ao_slot, ao_cnt,
+			                   c.root, c.spp, p.ao_radius, p.seed, c.ao);
+			if (any_hit_counted(sh->scene, c.ao, cap * c.spp, ao_cnt, c.spp, c.ao_occ, st, who)) return -1;
 		}
-		hipLaunchKernelGGL(k_shade_post, grid_for(slots), dim3(256), 0, st, S, c.rays[g], c.hits, slots, last, c.branch, c.spp, c.shadowed, ao_occ,
-		                   c.nodes[g], child);
-		slots *= c.branch;
-		per_root *= c.branch;
-		path0 *= 2;
+		hipLaunchKernelGGL(k_shade_post, grid_for(sh, cap), dim3(256), 0, st, S, c.rays[g], c.hits, cnt, last, c.spp, c.shadowed, c.ao_occ,
+		                   c.nodes[g], kid_cnt, kid_rays, kid_nodes);
+		cap *= c.branch;
 	}
 	for (int g = (int)c.levels - 2; g >= 0; --g) {
 		uint64_t sl = n;
 		for (int q = 0; q < g; ++q) sl *= c.branch;
-		hipLaunchKernelGGL(k_fold, grid_for(sl), dim3(256), 0, st, c.nodes[g], c.nodes[g + 1], sl, c.branch);
+		hipLaunchKernelGGL(k_fold, grid_for(sh, sl), dim3(256), 0, st, c.nodes[g], c.nodes[g + 1], c.counts + g);
 	}
 	return launch_check(who);
 }
@@ -481,7 +568,7 @@ int rtmi_trace_dev(rtmi_shader *sh, const rtmi_ray *d_rays, uint64_t n, uint32_t
 	if (!d_rays || !d_rgb) return fail(std::string(who) + ": NULL argument");
 	hipStream_t st = (hipStream_t)stream;
 	if (generation > params->max_tree_depth) { // scene.cpp:134-137
-		hipLaunchKernelGGL(k_fill_colour, grid_for(n), dim3(256), 0, st, n, 0.0, 0.0, 0.0, d_rgb);
+		hipLaunchKernelGGL(k_fill_colour, grid_for(sh, n), dim3(256), 0, st, n, 0.0, 0.0, 0.0, d_rgb);
 		return launch_check(who);
 	}
 	Chunk c;
@@ -490,9 +577,9 @@ int rtmi_trace_dev(rtmi_shader *sh, const rtmi_ray *d_rays, uint64_t n, uint32_t
 		const uint64_t m = std::min<uint64_t>(c.cap, n - at);
 		if (hipMemcpyAsync(c.rays[0], d_rays + at, m * sizeof(rtmi_ray), hipMemcpyDeviceToDevice, st) != hipSuccess)
 			return fail(std::string(who) + ": copy of the rays failed");
-		hipLaunchKernelGGL(k_batch_roots, grid_for(m), dim3(256), 0, st, first_index + at, m, c.root);
+		hipLaunchKernelGGL(k_batch_roots, grid_for(sh, m), dim3(256), 0, st, first_index + at, m, c.root);
 		if (run_chunk(sh, c, m, *params, st, who)) return -1;
-		hipLaunchKernelGGL(k_emit, grid_for(m), dim3(256), 0, st, c.nodes[0], c.root, m, first_index, d_rgb, (uint8_t *)nullptr);
+		hipLaunchKernelGGL(k_emit, grid_for(sh, m), dim3(256), 0, st, c.nodes[0], c.root, m, first_index, d_rgb, (uint8_t *)nullptr);
 	}
 	return launch_check(who);
 }
@@ -520,9 +607,9 @@ int rtmi_render_frame_dev(rtmi_shader *sh, const rtmi_camera *cam, double sx, do
 	if (plan_chunk(sh, n, params->max_tree_depth, params->ao_rays, c, who)) return -1;
 	for (uint64_t at = 0; at < n; at += c.cap) {
 		const uint64_t m = std::min<uint64_t>(c.cap, n - at);
-		hipLaunchKernelGGL(k_frame_rays, grid_for(m), dim3(256), 0, st, *cam, sx, sy, g, at, m, c.rays[0], c.root);
+		hipLaunchKernelGGL(k_frame_rays, grid_for(sh, m), dim3(256), 0, st, *cam, sx, sy, g, at, m, c.rays[0], c.root);
 		if (run_chunk(sh, c, m, *params, st, who)) return -1;
-		hipLaunchKernelGGL(k_emit, grid_for(m), dim3(256), 0, st, c.nodes[0], c.root, m, (uint64_t)0, d_rgb, d_pixels);
+		hipLaunchKernelGGL(k_emit, grid_for(sh, m), dim3(256), 0, st, c.nodes[0], c.root, m, (uint64_t)0, d_rgb, d_pixels);
 	}
 	return launch_check(who);
 }
@@ -531,7 +618,7 @@ int rtmi_tone_map_dev(const double *d_rgb, uint64_t n, uint8_t *d_pixels, void *
 	const char *who = "rtmi_tone_map_dev";
 	if (n == 0) return 0;
 	if (!d_rgb || !d_pixels) return fail(std::string(who) + ": NULL argument");
-	hipLaunchKernelGGL(k_tone_map, grid_for(3 * n), dim3(256), 0, (hipStream_t)stream, d_rgb, 3 * n, d_pixels);
+	hipLaunchKernelGGL(k_tone_map, dim3((uint32_t)std::min<uint64_t>(2048, (3 * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_rgb, 3 * n, d_pixels);
 	return launch_check(who);
 }
 

@@ -34,11 +34,13 @@ __device__ __forceinline__ rtmi_hit hit_record(const SceneDev &S, const HitQ &h)
 // (trace_queue); callers that care about coherence sort the buffer first.
 template <bool ANY>
 RTMI_TRAVERSAL_KERNEL void k_trace_rays(SceneDev S, const rtmi_ray *__restrict__ rays,
-                                                       uint64_t n, int *__restrict__ counter, Tune tune, rtmi_hit *__restrict__ out,
+                                                       uint64_t n, const uint32_t *__restrict__ d_n, uint32_t mul,
+                                                       int *__restrict__ counter, Tune tune, rtmi_hit *__restrict__ out,
                                                        uint8_t *__restrict__ occluded) {
 	extern __shared__ int stack[];
 	const uint64_t base = 0;
-	const uint32_t items = (uint32_t)n;
+	// d_n: the number of rays is known only on the device (a compacted wavefront): min(n, *d_n · mul)
+	const uint32_t items = d_n ? (uint32_t)min((unsigned long long)n, (unsigned long long)*d_n * mul) : (uint32_t)n;
 	auto fetch = [&](uint32_t idx, RayD &R) {
 		const rtmi_ray q = rays[base + idx];
 		if (q.reserved != 0.0) { // an inactive slot of a wavefront (e.g. the shadow ray of a pixel that hit nothing)
@@ -365,7 +367,7 @@ static uint32_t persistent_grid(rtmi_scene *s, K kernel, uint64_t n_items) {
 
 template <bool ANY>
 static int trace_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, rtmi_hit *d_out, uint8_t *d_occ, void *stream,
-                     const char *who) {
+                     const char *who, const uint32_t *d_n = nullptr, uint32_t mul = 1) {
 	if (check_scene(s, who)) return -1;
 	if (n == 0) return 0;
 	if (!d_rays || (ANY ? !d_occ : !d_out)) return fail(std::string(who) + ": NULL buffer");
@@ -377,9 +379,19 @@ static int trace_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, rtmi_hit
 	// occlusion rays are often short (an AO ray with tmax = 2 rarely gets past the top of the tree): fetching their
 	// successors pays only for larger groups of lanes (C4 room, 33 M AO rays: 2.21 ms at 16, 1.82 ms at 48; heavy occlusion rays prefer 16: 32 is the compromise)
 	if (ANY) tune.thresh = (int)std::min(64u, env_uint("RTMI_REFILL_ANY", 32));
-	hipLaunchKernelGGL(k_trace_rays<ANY>, dim3(grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, d_rays, n, slot,
-	                   tune, d_out, d_occ);
+	hipLaunchKernelGGL(k_trace_rays<ANY>, dim3(grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, d_rays, n, d_n, mul,
+	                   slot, tune, d_out, d_occ);
 	return launch_check(who);
+}
+
+// for the other translation units: the same launches with the ray count read on the device (see k_trace_rays)
+int closest_hit_counted(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t cap, const uint32_t *d_n, uint32_t mul, rtmi_hit *d_out,
+                        void *stream, const char *who) {
+	return trace_dev<false>(s, d_rays, cap, d_out, nullptr, stream, who, d_n, mul);
+}
+int any_hit_counted(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t cap, const uint32_t *d_n, uint32_t mul, uint8_t *d_occ,
+                    void *stream, const char *who) {
+	return trace_dev<true>(s, d_rays, cap, nullptr, d_occ, stream, who, d_n, mul);
 }
 
 // host-pointer convenience wrappers: stage through device buffers, synchronous
