@@ -440,10 +440,9 @@ __device__ __forceinline__ void set_ray(rtmi_ray &q, D3 org, D3 dir, double tmax
 	q.reserved = 0.0;
 }
 
-// One ambient-occlusion ray of findOcclusionNew (shader.cpp:140-232) at surface point P with hit.normal nrm: the
-// square point (a, b) comes from the 64-bit hash hsh (the reference draws it from an unseeded mt19937, :148-150,177).
-__device__ __forceinline__ void ao_ray(D3 P, D3 nrm, double R, uint64_t hsh, D3 &org, D3 &dir) {
-	const D3 Z = unit(nrm); // :153
+// findOcclusionNew (shader.cpp:140-232): the hemisphere frame of hit.normal (:153-171) ...
+__device__ __forceinline__ void ao_frame(D3 nrm, D3 &X, D3 &Y, D3 &Z) {
+	Z = unit(nrm); // :153
 	D3 t = Z;
 	const double cz = fabs(Z.z), cx = fabs(Z.x), cy = fabs(Z.y);
 	if (cz <= cx) { // :160-168, the reference's own branch structure
@@ -451,8 +450,12 @@ __device__ __forceinline__ void ao_ray(D3 P, D3 nrm, double R, uint64_t hsh, D3 
 	} else if (cx <= cz) {
 		if (cx <= cy) t.x = 1;
 	} else t.y = 1;
-	const D3 X = unit(cross(t, Z)); // :170
-	const D3 Y = cross(Z, X);       // :171
+	X = unit(cross(t, Z)); // :170
+	Y = cross(Z, X);       // :171
+}
+// ... and one ray in it: the square point (a, b) comes from the 64-bit hash hsh (the reference draws it from an
+// unseeded mt19937, :148-150,177).
+__device__ __forceinline__ void ao_ray_in_frame(D3 P, D3 X, D3 Y, D3 Z, double R, uint64_t hsh, D3 &org, D3 &dir) {
 	const double a = (2.0 * ((double)(hsh >> 11) * 0x1.0p-53)) - 1.0; // dis(gen) − 1, dis = uniform(0, 2)
 	const double b = (2.0 * ((double)(wf_mix64(hsh) >> 11) * 0x1.0p-53)) - 1.0;
 	double phi, r;
@@ -469,6 +472,11 @@ __device__ __forceinline__ void ao_ray(D3 P, D3 nrm, double R, uint64_t hsh, D3 
 	const double leg = (R * R) - (lb * lb);                        // :212
 	dir = unit(((leg / R) * Z) + base);                            // :214,218
 	org = P + (.0001 * dir);                                       // :220
+}
+__device__ __forceinline__ void ao_ray(D3 P, D3 nrm, double R, uint64_t hsh, D3 &org, D3 &dir) {
+	D3 X, Y, Z;
+	ao_frame(nrm, X, Y, Z);
+	ao_ray_in_frame(P, X, Y, Z, R, hsh, org, dir);
 }
 
 } // namespace rtmi

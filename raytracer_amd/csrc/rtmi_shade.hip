@@ -40,7 +40,7 @@ struct ShadeDev {
 
 enum : uint32_t { kDead = 0, kFinal = 1, kOpaque = 2, kReflect = 3, kRefract = 4, kTir = 5 };
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-struct Node { // 80 bytes per slot
+struct Node { // 72 bytes per slot
 	double c[3];    // colour (local until folded, then final)
 	double coef[3]; // reflectivity (kReflect) or translucency weights (kRefract, kTir)
 	double beer;    // Schlick weight of the reflected child (kRefract)
@@ -48,8 +48,6 @@ struct Node { // 80 bytes per slot
 	uint32_t child;    // first child's slot in the next generation (kReflect, kTir: 1 child; kRefract: 2)
 	uint32_t rootslot; // slot of the generation-1 ray this node descends from -> root[] = its ray index
 	uint32_t path;     // 1 = that ray itself, 2p = reflected child of p, 2p+1 = refracted child of p
-	uint32_t ao_at;    // position in the AO list, kNone if no AO ray is shot for this node
-	uint32_t pad;
 };
 
 constexpr double kEpsilon = 1.0e-5; // Render2/base.h:57
@@ -64,30 +62,44 @@ __device__ __forceinline__ double min3(double x, double y, double z) {          
 	if (y <= z) return y;
 	return z;
 }
+// one out-of-line copy of the library's pow: eight inlined copies cost k_shade_post its registers
+__device__ __attribute__((noinline)) double pow_ref(double x, double y) { return pow(x, y); }
+__device__ __attribute__((noinline)) double exp_ref(double x) { return exp(x); }
 __device__ __forceinline__ bool refracts(const rtmi_material &m) { // shader.cpp:542
 	return m.translucency[2] > 0.0 && m.translucency[1] > 0.0 && m.translucency[0] > 0.0;
 }
 __device__ __forceinline__ bool nonzero(const double *c) { return c[0] != 0.0 || c[1] != 0.0 || c[2] != 0.0; }
 
-// Every lane of the wave calls this (converged code) with the number of slots it needs (0, 1 or 2); returns the lane's
-// first slot.  One atomic per wave.
+// Every thread of the workgroup calls this (converged code, block-uniform loops) with the number of slots it needs
+// (0, 1 or 2); returns the thread's first slot.  One atomic per workgroup: atomics that return a value serialise on one
+// address (about 8 ns each on this part), so the reserving kernels run 1024-thread workgroups.
+constexpr uint32_t kReserveBlock = 1024;
 __device__ __forceinline__ uint32_t reserve(uint32_t *counter, uint32_t need) {
+	__shared__ uint32_t s_tot[kReserveBlock / 64];
+	__shared__ uint32_t s_base;
 	const unsigned long long b1 = __ballot(need >= 1), b2 = __ballot(need >= 2);
-	const uint32_t total = (uint32_t)(__popcll(b1) + __popcll(b2));
-	if (total == 0) return 0;
-	const uint32_t lane = threadIdx.x & 63u;
-	uint32_t base = 0;
-	if (lane == 0) base = atomicAdd(counter, total);
-	base = __shfl(base, 0, 64);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+	if (lane == 0) s_tot[wave] = (uint32_t)(__popcll(b1) + __popcll(b2));
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t sum = 0;
+		for (uint32_t w = 0; w < waves; ++w) sum += s_tot[w];
+		s_base = sum ? atomicAdd(counter, sum) : 0u;
+	}
+	__syncthreads();
+	uint32_t at = s_base;
+	for (uint32_t w = 0; w < wave; ++w) at += s_tot[w];
 	const unsigned long long lt = (1ull << lane) - 1ull;
-	return base + (uint32_t)(__popcll(b1 & lt) + __popcll(b2 & lt));
+	at += (uint32_t)(__popcll(b1 & lt) + __popcll(b2 & lt));
+	__syncthreads(); // s_tot / s_base are rewritten by the next step
+	return at;
 }
 
-// Elementwise kernels run a fixed grid and stride over the items; the item count is read on the device.  A wave handles
-// 64 consecutive items per step so that reserve() sees whole waves.
-#define RTMI_FOR_ITEMS(k, in, count)                                                                              \
-	for (uint64_t k##_b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ull, k = k##_b + (threadIdx.x & 63u); \
-	     k##_b < (count); k##_b += (uint64_t)gridDim.x * blockDim.x, k += (uint64_t)gridDim.x * blockDim.x)         \
+// Elementwise kernels run a fixed grid and stride over the items; the item count is read on the device.  The loop
+// bound is uniform over the workgroup (reserve() synchronises it); `in` tells a thread whether its item exists.
+#define RTMI_FOR_ITEMS(k, in, count)                                                                          \
+	for (uint64_t k##_b = (uint64_t)blockIdx.x * blockDim.x, k = k##_b + threadIdx.x; k##_b < (count);        \
+	     k##_b += (uint64_t)gridDim.x * blockDim.x, k += (uint64_t)gridDim.x * blockDim.x)                      \
 		if (const bool in = k < (count); true)
 
 // Generation-1 rays of a frame, rasterizer.cpp:230.  Items enumerate this rank's tiles (tile_first, + tile_stride, ...),
@@ -114,7 +126,7 @@ __global__ void k_set_counts(uint32_t *counts, uint32_t n_counters, uint32_t n) 
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k < n_counters) counts[k] = k == 0 ? n : 0u;
 }
-__global__ void k_frame_rays(rtmi_camera cam, double sx, double sy, FrameGrid g, uint64_t item0, uint64_t n,
+__global__ void __launch_bounds__(256) k_frame_rays(rtmi_camera cam, double sx, double sy, FrameGrid g, uint64_t item0, uint64_t n,
                              rtmi_ray *__restrict__ rays, uint64_t *__restrict__ root) {
 	RTMI_FOR_ITEMS(k, in, n) {
 		if (!in) continue;
@@ -140,29 +152,31 @@ __global__ void k_batch_roots(uint64_t first, uint64_t n, uint64_t *__restrict__
 // Everything of Shade that needs no secondary-ray answer: classify the slot, refraction (shader.cpp:542-641), the
 // shadow ray (:116-127).  `last`: the children would be generation max_tree_depth+1, for which Trace returns the
 // termination colour without casting (scene.cpp:134-137), so they are folded in at once.
-__global__ void k_shade_pre(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
+__global__ void __launch_bounds__(kReserveBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) k_shade_pre(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
                             const uint32_t *__restrict__ d_count, int first, int last, Node *__restrict__ nodes,
-                            rtmi_ray *__restrict__ shadow, uint32_t *__restrict__ kid_count, rtmi_ray *__restrict__ kid_rays,
-                            Node *__restrict__ kid_nodes) {
+                            rtmi_ray *__restrict__ shadow, uint8_t *__restrict__ wants_ao, uint32_t *__restrict__ kid_count,
+                            rtmi_ray *__restrict__ kid_rays, Node *__restrict__ kid_nodes) {
 	const uint64_t count = *d_count;
 	RTMI_FOR_ITEMS(k, in, count) {
-		Node nd;
-		nd.c[0] = nd.c[1] = nd.c[2] = 0.0; nd.coef[0] = nd.coef[1] = nd.coef[2] = 0.0; nd.beer = 0.0;
-		nd.kind = kDead; nd.child = kNone; nd.ao_at = kNone; nd.pad = 0;
-		nd.rootslot = first ? (uint32_t)k : (in ? nodes[k].rootslot : 0u);
-		nd.path = first ? 1u : (in ? nodes[k].path : 0u);
-		rtmi_ray sh, c0, c1;
-		inactive(sh);
+		// the node and the rays stay in registers until they are stored (no local structs: they would live in scratch)
+		D3 ndc = d3(0, 0, 0), ndcoef = d3(0, 0, 0);
+		double ndbeer = 0.0;
+		uint32_t ndkind = kDead;
+		const uint32_t rootslot = first ? (uint32_t)k : (in ? nodes[k].rootslot : 0u);
+		const uint32_t path = first ? 1u : (in ? nodes[k].path : 0u);
+		D3 sh_o = d3(0, 0, 0), sh_d = d3(0, 0, 0), c0_o = d3(0, 0, 0), c0_d = d3(0, 0, 0), c1_o = d3(0, 0, 0), c1_d = d3(0, 0, 0);
+		bool has_shadow = false;
 		uint32_t need = 0;
+		uint8_t ao = 0; // an AO answer would be used: opaque, ambient != 0 (and not shadowed: k_ao_list)
 		if (in) {
-			const rtmi_ray r = rays[k];
+			const rtmi_ray &r = rays[k];
 			if (r.reserved == 0.0) {
 				const rtmi_hit h = hits[k];
 				if (h.tri == RTMI_MISS) {
-					nd.kind = kFinal;
-					st(nd.c, background()); // scene.cpp:151
+					ndkind = kFinal;
+					ndc = background(); // scene.cpp:151
 				} else {
-					const rtmi_material m = S.mats[h.object];
+					const rtmi_material &m = S.mats[h.object];
 					const D3 Ns = ld(S.normals + 3 * (size_t)h.tri); // hit.normal = triNormal, object.cpp:17
 					const D3 P = hit_point(r, S.v1_orig + 3 * (size_t)h.tri, Ns);
 					if (refracts(m)) {
@@ -183,7 +197,7 @@ __global__ void k_shade_pre(ShadeDev S, const rtmi_ray *__restrict__ rays, const
 							refractionCoef = dot(E, Ns);
 							transl = d3(1, 1, 1);
 						} else { // :589-625
-							transl = d3(exp(-1.0 * transl.x * h.t), exp(-1.0 * transl.y * h.t), exp(-1.0 * transl.z * h.t));
+							transl = d3(exp_ref(-1.0 * transl.x * h.t), exp_ref(-1.0 * transl.y * h.t), exp_ref(-1.0 * transl.z * h.t));
 							const double dn = dot(mE, mN);
 							const D3 cosRefract = (mE - (dn * mN)) / kk;
 							const double cosSq = 1 - ((1 - (dn * dn)) / (kk * kk));
@@ -193,102 +207,104 @@ __global__ void k_shade_pre(ShadeDev S, const rtmi_ray *__restrict__ rays, const
 								refractionCoef = dot(tRefr, Ns);
 							}
 						}
-						st(nd.coef, transl);
+						ndcoef = transl;
 						if (tir) {
-							if (last) { nd.kind = kFinal; st(nd.c, cmul(transl, termination())); }
-							else { nd.kind = kTir; need = 1; set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY); }
+							if (last) { ndkind = kFinal; ndc = cmul(transl, termination()); }
+							else { ndkind = kTir; need = 1; c0_o = P + (kEpsilon * R); c0_d = R; }
 						} else {
 							const double beerR0 = ((1 - kk) * (1 - kk)) / ((1 + kk) * (1 + kk));         // :627
-							const double beerR = beerR0 + (1 - beerR0) * pow(1 - refractionCoef, 5.0); // :628
-							nd.beer = beerR;
+							const double beerR = beerR0 + (1 - beerR0) * pow_ref(1 - refractionCoef, 5.0); // :628
+							ndbeer = beerR;
 							if (last) {
-								nd.kind = kFinal;
-								st(nd.c, cmul(transl, (beerR * termination()) + ((1 - beerR) * termination()))); // :640
+								ndkind = kFinal;
+								ndc = cmul(transl, (beerR * termination()) + ((1 - beerR) * termination())); // :640
 							} else {
-								nd.kind = kRefract;
+								ndkind = kRefract;
 								need = 2;
-								set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY);         // :630-633
-								set_ray(c1, P + (kEpsilon * tRefr), tRefr, RTMI_INFINITY); // :635-638
+								c0_o = P + (kEpsilon * R); c0_d = R;         // :630-633
+								c1_o = P + (kEpsilon * tRefr); c1_d = tRefr; // :635-638
 							}
 						}
 					} else {
-						nd.kind = kOpaque; // colour and reflection: k_shade_post
-						set_ray(sh, P + (0.01 * Ns), unit(ld(S.lights[0].center) - P), RTMI_INFINITY); // :122,127
+						ndkind = kOpaque; // colour and reflection: k_shade_post
+						ao = nonzero(m.ambient) ? 1 : 0;
+						has_shadow = true;
+						sh_o = P + (0.01 * Ns); sh_d = unit(ld(S.lights[0].center) - P); // :122,127
 					}
 				}
 			}
 		}
 		const uint32_t at = reserve(kid_count, need);
 		if (need) {
-			nd.child = at;
-			kid_rays[at] = c0;
-			kid_nodes[at].rootslot = nd.rootslot; kid_nodes[at].path = 2u * nd.path;
+			set_ray(kid_rays[at], c0_o, c0_d, RTMI_INFINITY);
+			kid_nodes[at].rootslot = rootslot; kid_nodes[at].path = 2u * path;
 			if (need == 2) {
-				kid_rays[at + 1] = c1;
-				kid_nodes[at + 1].rootslot = nd.rootslot; kid_nodes[at + 1].path = 2u * nd.path + 1u;
+				set_ray(kid_rays[at + 1], c1_o, c1_d, RTMI_INFINITY);
+				kid_nodes[at + 1].rootslot = rootslot; kid_nodes[at + 1].path = 2u * path + 1u;
 			}
 		}
 		if (in) {
-			nodes[k] = nd;
-			shadow[k] = sh;
+			Node &nd = nodes[k];
+			st(nd.c, ndc); st(nd.coef, ndcoef);
+			nd.beer = ndbeer; nd.kind = ndkind; nd.child = need ? at : kNone; nd.rootslot = rootslot; nd.path = path;
+			if (has_shadow) set_ray(shadow[k], sh_o, sh_d, RTMI_INFINITY);
+			else inactive(shadow[k]);
+			wants_ao[k] = ao;
 		}
 	}
 }
 
-// The nodes whose AO answer will be used: opaque, not shadowed, ambient != 0.
-__global__ void k_ao_list(ShadeDev S, const rtmi_hit *__restrict__ hits, const uint32_t *__restrict__ d_count,
-                          const uint8_t *__restrict__ shadowed, Node *__restrict__ nodes, uint32_t *__restrict__ ao_count,
-                          uint32_t *__restrict__ ao_slot) {
+// The AO list: nodes whose AO answer will be used (k_shade_pre's flag, and not shadowed).  ao_at[k] = position or kNone.
+__global__ void __launch_bounds__(kReserveBlock) k_ao_list(const uint32_t *__restrict__ d_count, const uint8_t *__restrict__ wants_ao,
+                                                          const uint8_t *__restrict__ shadowed, uint32_t *__restrict__ ao_at,
+                                                          uint32_t *__restrict__ ao_count, uint32_t *__restrict__ ao_slot) {
 	const uint64_t count = *d_count;
 	RTMI_FOR_ITEMS(k, in, count) {
-		const uint32_t need = (in && nodes[k].kind == kOpaque && !shadowed[k] && nonzero(S.mats[hits[k].object].ambient)) ? 1u : 0u;
+		const uint32_t need = (in && wants_ao[k] && !shadowed[k]) ? 1u : 0u;
 		const uint32_t at = reserve(ao_count, need);
-		if (need) {
-			nodes[k].ao_at = at;
-			ao_slot[at] = (uint32_t)k;
-		}
+		if (in) ao_at[k] = need ? at : kNone;
+		if (need) ao_slot[at] = (uint32_t)k;
 	}
 }
 
-// findOcclusionNew's rays (shader.cpp:140-232), spp per listed node.  Square points: stream
-// (mix64(seed ^ path), root ray index, sample).
-__global__ void k_node_ao_rays(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
-                               const Node *__restrict__ nodes, const uint32_t *__restrict__ ao_slot,
-                               const uint32_t *__restrict__ ao_count, const uint64_t *__restrict__ root, uint32_t spp, double R,
-                               uint64_t seed, rtmi_ray *__restrict__ out) {
-	const uint64_t count = (uint64_t)*ao_count * spp;
-	RTMI_FOR_ITEMS(idx, in, count) {
+// findOcclusionNew's rays (shader.cpp:140-232), spp per listed node: one thread per node (hit point and hemisphere
+// frame once), rays at[·spp + s].  Square points: stream (mix64(seed ^ path), root ray index, sample).
+__global__ void __launch_bounds__(256) k_node_ao_rays(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
+                                                      const Node *__restrict__ nodes, const uint32_t *__restrict__ ao_slot,
+                                                      const uint32_t *__restrict__ ao_count, const uint64_t *__restrict__ root,
+                                                      uint32_t spp, double R, uint64_t seed, rtmi_ray *__restrict__ out) {
+	const uint64_t count = *ao_count;
+	RTMI_FOR_ITEMS(at, in, count) {
 		if (!in) continue;
-		const uint32_t at = (uint32_t)(idx / spp), s = (uint32_t)(idx - (uint64_t)at * spp);
 		const uint32_t k = ao_slot[at];
 		const rtmi_hit h = hits[k];
 		const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
 		const D3 P = hit_point(rays[k], S.v1_orig + 3 * (size_t)h.tri, Ns);
-		const uint64_t hsh = wf_mix64(wf_mix64(wf_mix64(seed ^ (uint64_t)nodes[k].path) ^ root[nodes[k].rootslot]) ^ (uint64_t)s);
-		D3 org, dir;
-		ao_ray(P, Ns, R, hsh, org, dir);
-		rtmi_ray q;
-		set_ray(q, org, dir, R); // occluded ⇔ Cast ∧ distance < R (:226)
-		out[idx] = q;
+		D3 X, Y, Z;
+		ao_frame(Ns, X, Y, Z);
+		const uint64_t stream = wf_mix64(wf_mix64(seed ^ (uint64_t)nodes[k].path) ^ root[nodes[k].rootslot]);
+		for (uint32_t s = 0; s < spp; ++s) {
+			D3 org, dir;
+			ao_ray_in_frame(P, X, Y, Z, R, wf_mix64(stream ^ (uint64_t)s), org, dir);
+			set_ray(out[at * spp + s], org, dir, R); // occluded ⇔ Cast ∧ distance < R (:226)
+		}
 	}
 }
 
 // The colour of an opaque hit (shader.cpp:481-522) and its reflected child (:527-537, :643).
-__global__ void k_shade_post(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
+__global__ void __launch_bounds__(kReserveBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) k_shade_post(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
                              const uint32_t *__restrict__ d_count, int last, uint32_t spp, const uint8_t *__restrict__ shadowed,
-                             const uint8_t *__restrict__ ao_occ, Node *__restrict__ nodes, uint32_t *__restrict__ kid_count,
+                             const uint32_t *__restrict__ ao_at, const uint8_t *__restrict__ ao_occ, Node *__restrict__ nodes, uint32_t *__restrict__ kid_count,
                              rtmi_ray *__restrict__ kid_rays, Node *__restrict__ kid_nodes) {
 	const uint64_t count = *d_count;
 	RTMI_FOR_ITEMS(k, in, count) {
-		uint32_t need = 0;
-		rtmi_ray c0;
-		Node nd;
+		uint32_t need = 0, ndkind = kFinal;
+		D3 c0_o = d3(0, 0, 0), c0_d = d3(0, 0, 0), ndc = d3(0, 0, 0), ndcoef = d3(0, 0, 0);
 		const bool mine = in && nodes[k].kind == kOpaque;
 		if (mine) {
-			nd = nodes[k];
-			const rtmi_ray r = rays[k];
+			const rtmi_ray &r = rays[k];
 			const rtmi_hit h = hits[k];
-			const rtmi_material m = S.mats[h.object];
+			const rtmi_material &m = S.mats[h.object];
 			const D3 diffuse = ld(m.diffuse), specular = ld(m.specular), ambient = ld(m.ambient), reflective = ld(m.reflectivity);
 			const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
 			const D3 P = hit_point(r, S.v1_orig + 3 * (size_t)h.tri, Ns);
@@ -299,9 +315,10 @@ __global__ void k_shade_post(ShadeDev S, const rtmi_ray *__restrict__ rays, cons
 				color = 0.7 * ambient; // :131-135
 			} else {
 				double occlusion = 1.0;
-				if (nd.ao_at != kNone) {
+				const uint32_t at = spp ? ao_at[k] : kNone;
+				if (at != kNone) {
 					int c = 0;
-					for (uint32_t s = 0; s < spp; ++s) c += ao_occ[(uint64_t)nd.ao_at * spp + s];
+					for (uint32_t s = 0; s < spp; ++s) c += ao_occ[(uint64_t)at * spp + s];
 					occlusion = (1.0 - (c / (double)spp)); // :231
 				}
 				for (uint32_t i = 0; i < S.n_lights; ++i) { // :485-519
@@ -312,47 +329,49 @@ __global__ void k_shade_post(ShadeDev S, const rtmi_ray *__restrict__ rays, cons
 						const D3 H = unit(L + E);
 						const double LH = dot(L, H), NH = dot(N, H);
 						const double g = sqrt((30.0 * 3016.0) - 1.0 + (LH * LH));
-						double Fresnel = 0.5 * pow(g - LH, 2.0) / pow(g + LH, 2.0);
-						Fresnel *= pow(LH * (g + LH) - 1.0, 2.0) / pow(LH * (g - LH) + 1.0, 2.0) + 1.0;
+						double Fresnel = 0.5 * pow_ref(g - LH, 2.0) / pow_ref(g + LH, 2.0);
+						Fresnel *= pow_ref(LH * (g + LH) - 1.0, 2.0) / pow_ref(LH * (g - LH) + 1.0, 2.0) + 1.0;
 						const double mm = 0.4;
-						double D = 1.0 / (4.0 * mm * mm * pow(NH, 4.0));
-						const double DPow = (pow(NH, 2.0) - 1.0) / ((mm * mm) * pow(NH, 2.0));
-						D = pow(D, DPow);
+						double D = 1.0 / (4.0 * mm * mm * pow_ref(NH, 4.0));
+						const double DPow = (pow_ref(NH, 2.0) - 1.0) / ((mm * mm) * pow_ref(NH, 2.0));
+						D = pow_ref(D, DPow);
 						const double G = min3(1.0, (2.0 * NH * NH) / LH, (2.0 * NH * dot(N, L)) / LH);
 						color = color + (((Fresnel * D * G) / (kPiRef * dot(N, E) * dot(N, L))) * (.7 * specular));
 					} else { // :510-518
 						const D3 RR = (-1.0 * L) + ((2.0 * dot(L, N)) * N);
-						color = color + cmul(emission, pow(max2(0.0, dot(E, RR)), m.phong_exp) * specular);
+						color = color + cmul(emission, pow_ref(max2(0.0, dot(E, RR)), m.phong_exp) * specular);
 					}
 				}
 			}
 			const D3 R = (-1.0 * E) + ((2.0 * dot(E, Ns)) * Ns); // :532
 			if (last) {
-				nd.kind = kFinal;
-				st(nd.c, color + cmul(reflective, termination())); // :643 with scene.cpp:134-137
+				ndc = color + cmul(reflective, termination()); // :643 with scene.cpp:134-137
 			} else if (!nonzero(m.reflectivity)) {
-				nd.kind = kFinal; // colour + 0·Trace(...)
-				st(nd.c, color);
+				ndc = color; // colour + 0·Trace(...)
 			} else {
-				nd.kind = kReflect;
+				ndkind = kReflect;
 				need = 1;
-				st(nd.c, color);
-				st(nd.coef, reflective);
-				set_ray(c0, P + (kEpsilon * R), R, RTMI_INFINITY); // :534-535
+				ndc = color;
+				ndcoef = reflective;
+				c0_o = P + (kEpsilon * R); c0_d = R; // :534-535
 			}
 		}
 		const uint32_t at = reserve(kid_count, need);
 		if (need) {
-			nd.child = at;
-			kid_rays[at] = c0;
-			kid_nodes[at].rootslot = nd.rootslot; kid_nodes[at].path = 2u * nd.path;
+			set_ray(kid_rays[at], c0_o, c0_d, RTMI_INFINITY);
+			kid_nodes[at].rootslot = nodes[k].rootslot; kid_nodes[at].path = 2u * nodes[k].path;
 		}
-		if (mine) nodes[k] = nd;
+		if (mine) {
+			Node &nd = nodes[k];
+			st(nd.c, ndc);
+			if (need) { st(nd.coef, ndcoef); nd.child = at; }
+			nd.kind = ndkind;
+		}
 	}
 }
 
 // Returns of Shade, deepest generation first: shader.cpp:614, :640, :643.
-__global__ void k_fold(Node *__restrict__ nodes, const Node *__restrict__ kids, const uint32_t *__restrict__ d_count) {
+__global__ void __launch_bounds__(256) k_fold(Node *__restrict__ nodes, const Node *__restrict__ kids, const uint32_t *__restrict__ d_count) {
 	const uint64_t count = *d_count;
 	RTMI_FOR_ITEMS(k, in, count) {
 		if (!in) continue;
@@ -377,7 +396,7 @@ __device__ __forceinline__ uint8_t tone(double c) {
 	const int v = (int)floor(256 * c);
 	return (uint8_t)(v >= 255 ? 255 : v);
 }
-__global__ void k_emit(const Node *__restrict__ nodes, const uint64_t *__restrict__ root, uint64_t n, uint64_t sub,
+__global__ void __launch_bounds__(256) k_emit(const Node *__restrict__ nodes, const uint64_t *__restrict__ root, uint64_t n, uint64_t sub,
                        double *__restrict__ rgb, uint8_t *__restrict__ pixels) {
 	RTMI_FOR_ITEMS(k, in, n) {
 		if (!in) continue;
@@ -401,9 +420,9 @@ __global__ void k_tone_map(const double *__restrict__ rgb, uint64_t n3, uint8_t 
 }
 
 // fixed grid for the striding elementwise kernels: enough waves to fill the device, never more than the items need
-static inline dim3 grid_for(const rtmi_shader *sh, uint64_t cap) {
-	const uint64_t full = (uint64_t)sh->scene->n_cus * 8u;
-	return dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full, (cap + 255) / 256)));
+static inline dim3 grid_for(const rtmi_shader *sh, uint64_t cap, uint32_t block = 256) {
+	const uint64_t full = (uint64_t)sh->scene->n_cus * (2048u / block);
+	return dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full, (cap + block - 1) / block)));
 }
 
 // One chunk of generation-1 rays through all generations.
@@ -415,8 +434,8 @@ struct Chunk {
 	std::vector<Node *> nodes;
 	rtmi_hit *hits;
 	rtmi_ray *shadow, *ao;
-	uint8_t *shadowed, *ao_occ;
-	uint32_t *ao_slot;
+	uint8_t *shadowed, *ao_occ, *wants_ao;
+	uint32_t *ao_slot, *ao_at;
 	uint64_t *root;
 	uint32_t *counts; // [0, levels]: nodes per generation (one spare), [levels+1, 2·levels]: AO-list length per generation
 };
@@ -431,7 +450,7 @@ static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t 
 	// bytes per generation-1 ray at capacity
 	double per = 8.0, s = 1.0, smax = 1.0;
 	for (uint32_t g = 0; g < levels; ++g) { per += s * (sizeof(rtmi_ray) + sizeof(Node)); smax = s; s *= c.branch; }
-	per += smax * (sizeof(rtmi_hit) + sizeof(rtmi_ray) + 1 + 4 + (double)c.spp * (sizeof(rtmi_ray) + 1));
+	per += smax * (sizeof(rtmi_hit) + sizeof(rtmi_ray) + 2 + 8 + (double)c.spp * (sizeof(rtmi_ray) + 1));
 	const double budget = (double)env_uint("RTMI_SHADE_WS_MB", 8192) * 1048576.0;
 	uint64_t cap = (uint64_t)(budget / per);
 	cap = std::max<uint64_t>(256, cap & ~(uint64_t)255);
@@ -453,7 +472,7 @@ static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t 
 	const uint64_t mx = c.slots[levels - 1];
 	const size_t o_hits = take(mx * sizeof(rtmi_hit)), o_sh = take(mx * sizeof(rtmi_ray)), o_shb = take(mx);
 	const size_t o_ao = take(c.spp ? mx * c.spp * sizeof(rtmi_ray) : 0), o_aob = take(c.spp ? mx * c.spp : 0);
-	const size_t o_aos = take(c.spp ? mx * sizeof(uint32_t) : 0);
+	const size_t o_aos = take(c.spp ? mx * sizeof(uint32_t) : 0), o_aoat = take(c.spp ? mx * sizeof(uint32_t) : 0), o_want = take(mx);
 	const size_t o_root = take(cap * sizeof(uint64_t));
 	const size_t o_counts = take((2 * levels + 2) * sizeof(uint32_t));
 	if (off > sh->ws_bytes) {
@@ -469,6 +488,8 @@ static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t 
 	c.ao = (rtmi_ray *)(sh->ws + o_ao);
 	c.ao_occ = (uint8_t *)(sh->ws + o_aob);
 	c.ao_slot = (uint32_t *)(sh->ws + o_aos);
+	c.ao_at = (uint32_t *)(sh->ws + o_aoat);
+	c.wants_ao = (uint8_t *)(sh->ws + o_want);
 	c.root = (uint64_t *)(sh->ws + o_root);
 	c.counts = (uint32_t *)(sh->ws + o_counts);
 	return 0;
@@ -486,17 +507,18 @@ static int run_chunk(rtmi_shader *sh, const Chunk &c, uint64_t n, const rtmi_tra
 		rtmi_ray *kid_rays = last ? nullptr : c.rays[g + 1];
 		Node *kid_nodes = last ? nullptr : c.nodes[g + 1];
 		if (closest_hit_counted(sh->scene, c.rays[g], cap, cnt, 1, c.hits, st, who)) return -1;
-		hipLaunchKernelGGL(k_shade_pre, grid_for(sh, cap), dim3(256), 0, st, S, c.rays[g], c.hits, cnt, g == 0 ? 1 : 0, last, c.nodes[g],
-		                   c.shadow, kid_cnt, kid_rays, kid_nodes);
+		hipLaunchKernelGGL(k_shade_pre, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, S, c.rays[g], c.hits, cnt, g == 0 ? 1 : 0, last,
+		                   c.nodes[g], c.shadow, c.wants_ao, kid_cnt, kid_rays, kid_nodes);
 		if (any_hit_counted(sh->scene, c.shadow, cap, cnt, 1, c.shadowed, st, who)) return -1;
 		if (c.spp) {
-			hipLaunchKernelGGL(k_ao_list, grid_for(sh, cap), dim3(256), 0, st, S, c.hits, cnt, c.shadowed, c.nodes[g], ao_cnt, c.ao_slot);
-			hipLaunchKernelGGL(k_node_ao_rays, grid_for(sh, cap * c.spp), dim3(256), 0, st, S, c.rays[g], c.hits, c.nodes[g], c.ao_slot, ao_cnt,
+			hipLaunchKernelGGL(k_ao_list, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, cnt, c.wants_ao, c.shadowed, c.ao_at, ao_cnt,
+			                   c.ao_slot);
+			hipLaunchKernelGGL(k_node_ao_rays, grid_for(sh, cap), dim3(256), 0, st, S, c.rays[g], c.hits, c.nodes[g], c.ao_slot, ao_cnt,
 			                   c.root, c.spp, p.ao_radius, p.seed, c.ao);
 			if (any_hit_counted(sh->scene, c.ao, cap * c.spp, ao_cnt, c.spp, c.ao_occ, st, who)) return -1;
 		}
-		hipLaunchKernelGGL(k_shade_post, grid_for(sh, cap), dim3(256), 0, st, S, c.rays[g], c.hits, cnt, last, c.spp, c.shadowed, c.ao_occ,
-		                   c.nodes[g], kid_cnt, kid_rays, kid_nodes);
+		hipLaunchKernelGGL(k_shade_post, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, S, c.rays[g], c.hits, cnt, last, c.spp,
+		                   c.shadowed, c.ao_at, c.ao_occ, c.nodes[g], kid_cnt, kid_rays, kid_nodes);
 		cap *= c.branch;
 	}
 	for (int g = (int)c.levels - 2; g >= 0; --g) {
