@@ -355,6 +355,64 @@ def main():
                   "gpu_Mrays_per_s": round(n1 / gpu_ms / 1e3, 1), "gpu_ms": round(gpu_ms, 4),
                   "same_hit_miss": same, "max_rel_distance_diff": dmax}
 
+    # ------------------------------------------------------------------ frames: Scene::Trace + Shader::Shade on the device
+    # (the caller of the ray queries.)  The shipped test1 frame (500x400, ambient 0.1, 10 AO rays,
+    # depth 1) beside the compiled reference's own Scene::Trace loop on the same scene, and a 1920x1080 frame of a
+    # 147 K-triangle studio.  Not part of `value`.
+    frame = None
+    if world == 1 and rank == 0 and not args.no_cpu:
+        from raytracer_amd import workloads as W
+
+        def frame_ms(sh, cam, reps):
+            n = cam.x_res * cam.y_res
+            rgb = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+            pix = torch.zeros(n, 3, dtype=torch.uint8, device="cuda")
+            sh.render_frame_dev(cam, rgb.data_ptr(), pix.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                sh.render_frame_dev(cam, rgb.data_ptr(), pix.data_ptr(), stream=stream)
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps, rgb
+
+        g6 = np.load(os.path.join(ROOT, "tests", "golden", "g6_shade_test1.npz"))
+        sc = rt.Scene(g6["tris"], g6["tri_obj"])
+        shd = rt.Shader(sc, g6["normals"], g6["mats"], g6["lights"], max_tree_depth=1, ao_rays=10)
+        cam6 = rt.Camera.from_cam14(g6["cam14"], g6["res"])
+        ms1, rgb1 = frame_ms(shd, cam6, 20)
+        frame = {"c1_frame": {"workload": "Render2/scenes/test1 as main.cpp renders it: 500x400, 10 AO rays + 1 shadow ray per hit, depth 1",
+                              "gpu_ms": round(ms1, 4), "gpu_Mpixels_per_s": round(0.2 / ms1 * 1e3, 1)}}
+        if c1 is not None and ok:
+            ref.set_materials(h, g6["mats"])
+            o6 = np.tile(g6["cam14"][:3], (int(g6["res"][0]) * int(g6["res"][1]), 1))
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            from oracle_py import Oracle as _O
+            _o = _O()
+            pix6 = np.array([(i, j) for i in range(int(g6["res"][1])) for j in range(int(g6["res"][0]))], np.uint32)
+            d6 = _o.primary_dirs(_o.raster_details(g6["cam14"], int(g6["res"][0]), int(g6["res"][1])), pix6)
+            secs, reps, ref_rgb = 0.0, 0, None
+            while secs < 5.0 and reps < 10:
+                ref_rgb, s_ = ref.trace(h, o6, d6)
+                secs += s_
+                reps += 1
+            dmax = float(np.abs(rgb1.cpu().numpy() - ref_rgb).max())
+            frame["c1_frame"].update({"reference_ms": round(1e3 * secs / reps, 1), "reference_cores": 1, "kind": "reference",
+                                      "sample": "%d frames of the compiled reference's Scene::Trace loop = %.1f s" % (reps, secs),
+                                      "max_colour_diff_to_reference": round(dmax, 4),
+                                      "note": "the reference draws its AO rays from an unseeded generator (colours may differ by multiples of 0.0085, at most 0.085); on this scene no AO ray is occluded, so 0.0 means the two frames are identical"})
+        vs, ob, ms_, ls = W.studio(64, 0.1)
+        sc2 = rt.Scene(vs, ob)
+        shd2 = rt.Shader(sc2, W.face_normals(vs), ms_, ls, max_tree_depth=1, ao_rays=10)
+        cam7 = rt.Camera.from_cam14(W.STUDIO_CAM14, (1920, 1080))
+        ms2, _ = frame_ms(shd2, cam7, 10)
+        shd3 = rt.Shader(sc2, W.face_normals(vs), ms_, ls, max_tree_depth=3, ao_rays=10)
+        ms3, _ = frame_ms(shd3, cam7, 5)
+        frame["studio_1080p"] = {"workload": "workloads.studio(64): %d triangles, 6 materials (Phong, microfacet, mirror, 2 refracting), 2 lights, 1920x1080, 10 AO rays" % len(vs),
+                                 "depth1_ms": round(ms2, 3), "depth1_Mpixels_per_s": round(1920 * 1080 / ms2 / 1e3, 1),
+                                 "depth3_ms": round(ms3, 3)}
+
     if rank == 0:
         line = {
             "metric": "closest-hit Mrays/s on 1M-tri scene; form-factor+solve time @64K patches",
@@ -369,7 +427,7 @@ def main():
                                "max_leaf": int(info.max_leaf_size), "build_seconds": round(info.build_seconds, 2),
                                "device_MB": round(info.device_bytes / 1e6, 1)}},
             "roofline": roofline, "roofline_traversal": roofline_traversal, "solver": solver, "formfactor": formfactor,
-            "cpu_baseline": cpu, "c1_reference": c1,
+            "cpu_baseline": cpu, "c1_reference": c1, "frame": frame,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -9,6 +9,8 @@
 //   rtmi_host::SceneBinding   Scene::BuildBSP (scene.cpp:463)  -> rtmi_scene_create over the ORIGINAL triangles
 //                             Scene::Cast (scene.cpp:159-207) + updateHitInfo (object.cpp:13-24) -> batch Cast()
 //                             Cast as a predicate (shader.cpp:131,226)                         -> Occluded()
+//   rtmi_host::ShaderBinding  Scene::Trace + Shader::Shade (scene.cpp:127-155, shader.cpp:395-645) and the pixel loop of
+//                             Rasterizer::Serial_Normal_Raster (rasterizer.cpp:191-241)            -> Trace(), Rasterize()
 //   rtmi_host::RadiosityBinding  findFormFactor / progressiveRefinement / setRadiosityForAllElements
 //                             (radiosity.cpp:335-467, 483-563, 122-134) on the element list
 #ifndef RTMI_ADAPTER_HPP
@@ -65,6 +67,7 @@ public:
 
 	rtmi_scene *handle() const { return scene_; }
 	size_t triangles() const { return tri_of_id_.size(); }
+	const TriT *triangle(size_t id) const { return tri_of_id_[id]; }
 
 	// Scene::Cast for a batch: found[i] = the reference's return value; hits[i] is filled exactly as
 	// updateHitInfo + Scene::Cast leave it (object.cpp:13-24, scene.cpp:197-203) and untouched on a miss.
@@ -132,6 +135,95 @@ private:
 	rtmi_scene *scene_ = nullptr;
 	std::vector<TriT *> tri_of_id_;
 	std::vector<const ObjectT *> object_of_tri_;
+};
+
+// ------------------------------------------------------------------------------------------------ shading
+// Scene::Trace / Shader::Shade / the raster loop on the device.  Materials are read from sceneObjects[k]->material
+// (Render2/ray_tracer.h:23-34), lights from scene.GetLight(i) exactly as Shade reads them: Center(GetBox(*light)) and
+// material->emission (shader.cpp:486-489) — GetBox and Center are the reference's own free functions (util.h), found
+// at instantiation.  Scene::max_tree_depth is honoured; AO rays and radius are Shade's constants (shader.cpp:481).
+template <class SceneT, class ObjectT, class TriT>
+class ShaderBinding {
+public:
+	ShaderBinding() = default;
+	ShaderBinding(const ShaderBinding &) = delete;
+	ShaderBinding &operator=(const ShaderBinding &) = delete;
+	~ShaderBinding() { rtmi_shader_destroy(shader_); }
+
+	bool bind(const SceneBinding<SceneT, ObjectT, TriT> &geometry, const SceneT &scene, uint32_t ao_rays = 10, double ao_radius = 2.0,
+	          uint64_t seed = 1) {
+		std::vector<double> nrm(3 * geometry.triangles());
+		for (size_t i = 0; i < geometry.triangles(); ++i) put3(&nrm[3 * i], geometry.triangle(i)->triNormal);
+		std::vector<rtmi_material> mats;
+		for (const ObjectT *o : scene.sceneObjects) {
+			rtmi_material m;
+			rgb(m.diffuse, o->material->diffuse); rgb(m.specular, o->material->specular); rgb(m.ambient, o->material->ambient);
+			rgb(m.reflectivity, o->material->reflectivity); rgb(m.translucency, o->material->translucency);
+			m.phong_exp = o->material->Phong_exp; m.ref_index = o->material->ref_index; m.roughness = o->material->microFacetsRoughness;
+			mats.push_back(m);
+		}
+		std::vector<rtmi_light> lights;
+		for (unsigned i = 0; i < scene.NumLights(); ++i) {
+			rtmi_light l;
+			put3(l.center, Center(GetBox(*scene.GetLight(i))));
+			rgb(l.emission, scene.GetLight(i)->material->emission);
+			lights.push_back(l);
+		}
+		params_.max_tree_depth = scene.max_tree_depth;
+		params_.ao_rays = ao_rays; params_.ao_radius = ao_radius; params_.seed = seed;
+		rtmi_shader_destroy(shader_);
+		shader_ = rtmi_shader_create(geometry.handle(), nrm.data(), mats.data(), (uint32_t)mats.size(), lights.data(), (uint32_t)lights.size());
+		return shader_ != nullptr;
+	}
+
+	// Color Scene::Trace(const Ray&) for a batch (rays[i].generation is honoured per batch: all rays of one call share
+	// rays[0].generation).  ColorT needs red, green, blue.
+	template <class RayT, class ColorT>
+	void Trace(const RayT *rays, size_t n, ColorT *out) const {
+		if (n == 0) return;
+		std::vector<rtmi_ray> r(n);
+		for (size_t i = 0; i < n; ++i) { put3(r[i].o, rays[i].origin); put3(r[i].d, rays[i].direction); r[i].tmax = RTMI_INFINITY; r[i].reserved = 0.0; }
+		Buffer d_rays(n * sizeof(rtmi_ray)), d_rgb(3 * n * sizeof(double));
+		if (hipMemcpy(d_rays.p, r.data(), n * sizeof(rtmi_ray), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("upload of the rays failed");
+		if (rtmi_trace_dev(shader_, (const rtmi_ray *)d_rays.p, n, (uint32_t)rays[0].generation, 0, &params_, (double *)d_rgb.p, nullptr) != 0) throw Error("rtmi_trace_dev");
+		std::vector<double> c(3 * n);
+		if (hipMemcpy(c.data(), d_rgb.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("download of the colours failed");
+		for (size_t i = 0; i < n; ++i) { out[i].red = c[3 * i]; out[i].green = c[3 * i + 1]; out[i].blue = c[3 * i + 2]; }
+	}
+
+	// The loop of Rasterizer::Serial_Normal_Raster (rasterizer.cpp:219-233): I(i, j) = ToneMap(scene.Trace(ray(i, j))).
+	// CameraT: Render2/ray_tracer.h:113-122; ImageT: PPM_Image (operator()(i, j) -> Pixel& with r, g, b).
+	template <class CameraT, class ImageT>
+	void Rasterize(const CameraT &cam, ImageT &I) const {
+		rtmi_camera c;
+		double eye[3], lookat[3], up[3];
+		put3(eye, cam.eye); put3(lookat, cam.lookat); put3(up, cam.up);
+		const double xw[2] = {cam.x_win.min, cam.x_win.max}, yw[2] = {cam.y_win.min, cam.y_win.max};
+		if (rtmi_camera_setup(eye, lookat, up, cam.vpdist, xw, yw, cam.x_res, cam.y_res, &c) != 0) throw Error("rtmi_camera_setup");
+		const size_t n = (size_t)cam.x_res * cam.y_res;
+		Buffer d_pix(3 * n);
+		if (rtmi_render_frame_dev(shader_, &c, 0.5, 0.5, 64, 64, 0, 1, &params_, nullptr, (uint8_t *)d_pix.p, nullptr) != 0) throw Error("rtmi_render_frame_dev");
+		std::vector<uint8_t> px(3 * n);
+		if (hipMemcpy(px.data(), d_pix.p, 3 * n, hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("download of the image failed");
+		for (unsigned i = 0; i < cam.y_res; ++i)
+			for (unsigned j = 0; j < cam.x_res; ++j) {
+				const uint8_t *p = &px[3 * ((size_t)i * cam.x_res + j)];
+				auto &dst = I(i, j);
+				dst.r = p[0]; dst.g = p[1]; dst.b = p[2];
+			}
+	}
+
+private:
+	struct Buffer {
+		void *p = nullptr;
+		explicit Buffer(size_t bytes) { if (hipMalloc(&p, bytes) != hipSuccess) throw std::runtime_error("hipMalloc failed"); }
+		~Buffer() { (void)hipFree(p); }
+		Buffer(const Buffer &) = delete;
+		Buffer &operator=(const Buffer &) = delete;
+	};
+	template <class ColorT> static void rgb(double *p, const ColorT &c) { p[0] = c.red; p[1] = c.green; p[2] = c.blue; }
+	rtmi_shader *shader_ = nullptr;
+	rtmi_trace_params params_ = {1, 10, 2.0, 1};
 };
 
 // ------------------------------------------------------------------------------------------------ radiosity

@@ -275,6 +275,11 @@ class Reference:
         self.lib.ref_get_lights(h, _p(out))
         return out
 
+    def set_materials(self, h, mats18):
+        mats18 = _f64(mats18, (-1, 18))
+        assert len(mats18) == self.lib.ref_num_objects(h)
+        self.lib.ref_set_materials(h, _p(mats18))
+
     def set_max_depth(self, h, depth):
         self.lib.ref_set_max_depth(h, C.c_uint(depth))
 

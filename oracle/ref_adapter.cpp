@@ -8,6 +8,7 @@
 #include "ray_tracer.h"
 #include "util.h"
 #include "radiosity_helper.h"
+#include "ppm_image.h"
 #include "ref_scene.h"
 
 #include "../include/rtmi_adapter.hpp"
@@ -18,6 +19,7 @@
 namespace {
 typedef rtmi_host::SceneBinding<Scene, Object, BSP_Node> Binding;
 typedef rtmi_host::RadiosityBinding<QuadTreeNode> RadBinding;
+typedef rtmi_host::ShaderBinding<Scene, Object, BSP_Node> ShadeBinding;
 inline Vec3 V(const double *p) { return Vec3(p[0], p[1], p[2]); }
 inline void put(double *p, const Vec3 &a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
 } // namespace
@@ -103,6 +105,45 @@ int ref_adapter_occluded(void *bind, long n, const double *o, const double *d, c
 		return -1;
 	}
 	return 0;
+}
+
+// Rasterizer::Rasterize's work through the adapter: the reference's Scene (materials, lights, max_tree_depth) and
+// Camera -> a PPM_Image filled on the GPU; pixels = x_res·y_res·3 bytes in the reference's row order.  Also Scene::Trace
+// on the frame's first n_probe primary rays -> probe_rgb (n_probe × 3), through the batch Trace().
+int ref_adapter_rasterize(void *h, void *bind, uint32_t ao_rays, uint64_t seed, uint8_t *pixels, long n_probe, const double *probe_o,
+                          const double *probe_d, double *probe_rgb) {
+	RefScene *s = (RefScene *)h;
+	try {
+		ShadeBinding sb;
+		if (!sb.bind(*(Binding *)bind, s->scene, ao_rays, 2.0, seed)) return -1;
+		PPM_Image I(s->cam.x_res, s->cam.y_res);
+		sb.Rasterize(s->cam, I);
+		for (unsigned i = 0; i < s->cam.y_res; ++i)
+			for (unsigned j = 0; j < s->cam.x_res; ++j) {
+				const Pixel &p = I(i, j);
+				uint8_t *q = pixels + 3 * ((size_t)i * s->cam.x_res + j);
+				q[0] = p.r; q[1] = p.g; q[2] = p.b;
+			}
+		std::vector<Ray> rays(n_probe);
+		std::vector<Color> cols(n_probe);
+		for (long k = 0; k < n_probe; ++k) {
+			rays[k].origin = V(probe_o + 3 * k); rays[k].direction = V(probe_d + 3 * k);
+			rays[k].type = generic_ray; rays[k].generation = 1;
+		}
+		sb.Trace(rays.data(), (size_t)n_probe, cols.data());
+		for (long k = 0; k < n_probe; ++k) { probe_rgb[3 * k] = cols[k].red; probe_rgb[3 * k + 1] = cols[k].green; probe_rgb[3 * k + 2] = cols[k].blue; }
+		return 0;
+	} catch (const std::exception &) {
+		return -1;
+	}
+}
+
+// the camera of a scene built from arrays (ref_scene_from_triangles / ref_scene_one_tri_objects have none)
+void ref_set_camera(void *h, const double *c14, uint32_t x_res, uint32_t y_res) {
+	Camera &cam = ((RefScene *)h)->cam;
+	cam.eye = V(c14); cam.lookat = V(c14 + 3); cam.up = V(c14 + 6);
+	cam.vpdist = c14[9]; cam.x_win.min = c14[10]; cam.x_win.max = c14[11]; cam.y_win.min = c14[12]; cam.y_win.max = c14[13];
+	cam.x_res = x_res; cam.y_res = y_res;
 }
 
 // Radiosity through the adapter on the reference's own element list (needs ref_rad_setup): fills FF_out (n × n doubles,

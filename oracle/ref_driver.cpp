@@ -342,6 +342,19 @@ void ref_get_lights(void *h, double *out) {
 		out[6 * i + 5] = L->material->emission.blue;
 	}
 }
+// overwrite every sceneObject's material (18 doubles each, as ref_scene_one_tri_objects)
+void ref_set_materials(void *h, const double *mats) {
+	long k = 0;
+	for (Object *o : ((RefScene *)h)->scene.sceneObjects) {
+		const double *m = mats + 18 * k++;
+		Material *mat = new Material();
+		mat->diffuse = Color(m[0], m[1], m[2]); mat->specular = Color(m[3], m[4], m[5]);
+		mat->ambient = Color(m[6], m[7], m[8]); mat->reflectivity = Color(m[9], m[10], m[11]);
+		mat->translucency = Color(m[12], m[13], m[14]); mat->emission = Black;
+		mat->Phong_exp = m[15]; mat->ref_index = m[16]; mat->microFacetsRoughness = m[17];
+		o->material = mat;
+	}
+}
 void ref_set_max_depth(void *h, unsigned d) { ((RefScene *)h)->scene.max_tree_depth = d; }
 
 // Scene::Trace (scene.cpp:127-155) on n rays of the given generation (1 = from the eye, rasterizer.cpp:217);

@@ -126,3 +126,52 @@ def test_adapter_radiosity_on_the_references_elements(ref, oracle, tmp_path):
     Bref = ref.rad_B(h)
     assert ref.rad_residual(h) <= 1e-5
     assert np.linalg.norm(B[:ne] - Bref[:ne]) / np.linalg.norm(Bref[:ne]) < 1e-4
+
+
+def adapter_rasterize(ref, h, b, res, ao_rays, seed, o, d):
+    px = np.zeros((int(res[1]), int(res[0]), 3), np.uint8)
+    rgb = np.zeros((len(o), 3))
+    rc = ref.lib.ref_adapter_rasterize(h, b, C.c_uint32(ao_rays), C.c_uint64(seed), _p(px), C.c_long(len(o)), _p(o), _p(d), _p(rgb))
+    assert rc == 0, ref.lib.ref_adapter_error()
+    return px, rgb
+
+
+def test_adapter_rasterize_beside_the_references_trace(ref, oracle, tmp_path):
+    """rtmi_host::ShaderBinding on the reference's own Scene / Camera / PPM_Image beside its own Scene::Trace + ToneMap
+    loop (rasterizer.cpp:219-233) on the same objects.
+    (1) test1 as shipped, through the reference's BSP: on that scene no AO ray is ever occluded, so the reference's
+        unseeded draw cannot show and the two images agree byte for byte;
+    (2) the studio scene (every Shade branch, max_tree_depth 3, ambient 0): colours within 1e-11, bytes equal except
+        where 256·c sits on an integer."""
+    from conftest import frame_rays
+    g = load_golden("g6_shade_test1.npz")
+    h = None
+    for _ in range(10):
+        h = ref.scene_from_triangles(g["tris"], g["tri_obj"], g["lights"][0, :3])
+        if ref.build_bsp(h, str(tmp_path)) == 0:
+            break
+    else:
+        pytest.skip("the reference's BSP build kept throwing")
+    ref.set_materials(h, g["mats"])
+    ref.lib.ref_set_camera(h, _p(np.ascontiguousarray(g["cam14"])), C.c_uint32(int(g["res"][0])), C.c_uint32(int(g["res"][1])))
+    b = C.c_void_p(ref.lib.ref_adapter_bind(h))
+    assert b, ref.lib.ref_adapter_error()
+    o, d, _ = frame_rays(oracle, g["cam14"], g["res"])
+    px, probe = adapter_rasterize(ref, h, b, g["res"], 10, 1, o[:5000], d[:5000])
+    want, _ = ref.trace(h, o, d)
+    assert np.array_equal(px.reshape(-1, 3), ref.tone_map(want))
+    assert np.array_equal(px.reshape(-1, 3), g["pixels"])
+    assert np.abs(probe - want[:5000]).max() < 1e-11
+
+    s = load_golden("g6_shade_studio.npz")
+    h2 = ref.scene_one_tri_objects(s["tris"], s["normals"], s["tri_obj"], s["mats"], s["lights"])
+    ref.set_max_depth(h2, 3)
+    ref.lib.ref_set_camera(h2, _p(np.ascontiguousarray(s["cam14"])), C.c_uint32(int(s["res"][0])), C.c_uint32(int(s["res"][1])))
+    b2 = C.c_void_p(ref.lib.ref_adapter_bind(h2))
+    assert b2, ref.lib.ref_adapter_error()
+    o, d, _ = frame_rays(oracle, s["cam14"], s["res"])
+    px2, probe2 = adapter_rasterize(ref, h2, b2, s["res"], 10, 1, o, d)
+    assert np.abs(probe2 - s["rgb_d3"]).max() < 1e-11
+    wp = ref.tone_map(s["rgb_d3"])
+    edge = np.abs(256 * s["rgb_d3"] - np.round(256 * s["rgb_d3"])) < 1e-8
+    assert not ((px2.reshape(-1, 3) != wp) & ~edge).any()
