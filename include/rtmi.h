@@ -185,6 +185,28 @@ int rtmi_trace_dev(rtmi_shader *, const rtmi_ray *d_rays, uint64_t n, uint32_t g
 int rtmi_render_frame_dev(rtmi_shader *, const rtmi_camera *cam, double sx, double sy, uint32_t tile_w, uint32_t tile_h,
                           uint32_t tile_first, uint32_t tile_stride, const rtmi_trace_params *params, double *d_rgb,
                           uint8_t *d_pixels, void *stream);
+/* The other two pixel loops of the reference's Rasterizer, same frame conventions:
+ *   RTMI_RASTER_ANTI_ALIASING    Rasterizer::Anti_Aliasing (Render2/rasterizer.cpp:297-349): 4 rays per pixel at
+ *                                (j + {.25,.75}, i + {.25,.75}), colours summed in the reference's loop order, / 4.0
+ *   RTMI_RASTER_DEPTH_OF_FIELD   Rasterizer::Depth_Of_Field_Effect (:351-406): lens_dim² rays per pixel from the lens
+ *                                grid eye + xLens·XGradation + yLens·YGradation toward the view plane re-aimed at lookat
+ *   RTMI_RASTER_NORMAL           the loop of rtmi_render_frame_dev (sample position sx, sy)
+ * rtmi_raster_setup fills the RasterDetails fields these loops read (:40-68: R, U, XGradation = Lwidth·R/7,
+ * YGradation = Lheight·U/7, DistLensDim 7).  Sample s of pixel p is ray p·S + s of the AO stream. */
+#define RTMI_RASTER_NORMAL 0u
+#define RTMI_RASTER_ANTI_ALIASING 1u
+#define RTMI_RASTER_DEPTH_OF_FIELD 2u
+typedef struct rtmi_raster {
+	uint32_t mode, lens_dim;
+	double sx, sy;
+	double lookat[3], R[3], U[3], x_gradation[3], y_gradation[3];
+	double vpdist, xmin, ymax;
+} rtmi_raster;
+int rtmi_raster_setup(uint32_t mode, const double eye[3], const double lookat[3], const double up[3], double vpdist,
+                      const double x_win[2], const double y_win[2], rtmi_raster *out);
+int rtmi_render_frame_sampled_dev(rtmi_shader *, const rtmi_camera *cam, const rtmi_raster *raster, uint32_t tile_w,
+                                  uint32_t tile_h, uint32_t tile_first, uint32_t tile_stride,
+                                  const rtmi_trace_params *params, double *d_rgb, uint8_t *d_pixels, void *stream);
 /* ToneMap (Render2/rasterizer.cpp:79-88) on n colours -> 3n bytes */
 int rtmi_tone_map_dev(const double *d_rgb, uint64_t n, uint8_t *d_pixels, void *stream);
 

@@ -8,6 +8,8 @@ Shader::Shade (scene.cpp:127-155, shader.cpp:395-645), before ToneMap, plus its 
                         (shader.cpp:148-150) cannot reach the colour -> reproducible to the bit; max_tree_depth 1 and 3.
                         rgb_amb: ambient 0.1, depth 1 -> each lit pixel is  A + occ·B  with occ = 1 − k/10 for the
                         reference's random k; the tests solve for k and require an integer in 0..10.
+  g6_raster_studio.npz  the same studio scene (ambient 0) through the reference's own Rasterizer::Anti_Aliasing (80x60,
+                        depth 3) and Rasterizer::Depth_Of_Field_Effect (48x36, depth 1): ToneMap bytes.
   g6_shade_test1.npz    scenes/test1 exactly as main.cpp renders it (BSP built by the reference, ambient 0.1, AO 10 rays):
                         all 200 000 ToneMap'ed pixels + colours of every 16th pixel.
 
@@ -53,6 +55,19 @@ rgb_amb, _ = ref.trace(ha, o, d)
 np.savez_compressed(os.path.join(GOLD, "g6_shade_studio.npz"), tris=verts, normals=nrm, tri_obj=obj, mats=mats, mats_amb=mats_a,
                     lights=lights, cam14=W.STUDIO_CAM14, res=np.array([XR, YR], np.uint32), rgb_amb=rgb_amb,
                     pixels_d1=ref.tone_map(out["rgb_d1"]), **out)
+
+# ---- the other raster loops: the reference's own Rasterizer::Anti_Aliasing / Depth_Of_Field_Effect ------------
+work2 = tempfile.mkdtemp()
+ras = {}
+for name, mode, res, depth in (("aa", 1, (80, 60), 3), ("dof", 2, (48, 36), 1)):
+    ref.set_camera(h, W.STUDIO_CAM14, res)
+    ref.set_max_depth(h, depth)
+    ras["pixels_" + name] = ref.raster(h, mode, work2, res)
+    ras["res_" + name] = np.array(res, np.uint32)
+    ras["depth_" + name] = depth
+    print("studio %s %dx%d depth %d: the reference's raster loop done" % (name, res[0], res[1], depth))
+np.savez_compressed(os.path.join(GOLD, "g6_raster_studio.npz"), **ras)
+shutil.rmtree(work2, ignore_errors=True)
 
 # ---- test1 as shipped ------------------------------------------------------------------------------------
 work = tempfile.mkdtemp()

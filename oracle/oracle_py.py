@@ -78,6 +78,16 @@ class Oracle:
         self.lib.rto_primary_dirs(_p(rd18), C.c_long(len(pix)), _p(pix), _p(d))
         return d
 
+    def raster_rays(self, mode, cam14, res, pix):
+        """(o, d, S): the S generation-1 rays per listed pixel of Serial_Normal_Raster (0), Anti_Aliasing (1),
+        Depth_Of_Field_Effect (2), in the reference's loop order"""
+        S = {0: 1, 1: 4, 2: 49}[mode]
+        cam14 = _f64(cam14); pix = np.ascontiguousarray(pix, np.uint32).reshape(-1, 2)
+        o = np.zeros((len(pix) * S, 3)); d = np.zeros((len(pix) * S, 3))
+        self.lib.rto_raster_rays(C.c_int(mode), _p(cam14), C.c_uint32(int(res[0])), C.c_uint32(int(res[1])), C.c_long(len(pix)),
+                                 _p(pix), _p(o), _p(d))
+        return o, d, S
+
     def hit_point(self, o, d, v1, nrm):
         o, d, v1, nrm = (_f64(x, (-1, 3)) for x in (o, d, v1, nrm))
         out = np.zeros_like(o)
@@ -279,6 +289,17 @@ class Reference:
         mats18 = _f64(mats18, (-1, 18))
         assert len(mats18) == self.lib.ref_num_objects(h)
         self.lib.ref_set_materials(h, _p(mats18))
+
+    def set_camera(self, h, cam14, res):
+        self.lib.ref_set_camera14(h, _p(_f64(cam14)), C.c_uint32(int(res[0])), C.c_uint32(int(res[1])))
+
+    def raster(self, h, mode, workdir, res):
+        """the reference's Normal_Raster (0) / Anti_Aliasing (1) / Depth_Of_Field_Effect (2) -> y x x x 3 ToneMap bytes"""
+        px = np.zeros((int(res[1]), int(res[0]), 3), np.uint8)
+        rc = self.lib.ref_raster(h, C.c_int(mode), workdir.encode(), _p(px))
+        if rc != 0:
+            raise RuntimeError("ref_raster: x_res must divide by 8 and y_res by 6")
+        return px
 
     def set_max_depth(self, h, depth):
         self.lib.ref_set_max_depth(h, C.c_uint(depth))

@@ -138,14 +138,6 @@ int ref_adapter_rasterize(void *h, void *bind, uint32_t ao_rays, uint64_t seed, 
 	}
 }
 
-// the camera of a scene built from arrays (ref_scene_from_triangles / ref_scene_one_tri_objects have none)
-void ref_set_camera(void *h, const double *c14, uint32_t x_res, uint32_t y_res) {
-	Camera &cam = ((RefScene *)h)->cam;
-	cam.eye = V(c14); cam.lookat = V(c14 + 3); cam.up = V(c14 + 6);
-	cam.vpdist = c14[9]; cam.x_win.min = c14[10]; cam.x_win.max = c14[11]; cam.y_win.min = c14[12]; cam.y_win.max = c14[13];
-	cam.x_res = x_res; cam.y_res = y_res;
-}
-
 // Radiosity through the adapter on the reference's own element list (needs ref_rad_setup): fills FF_out (n × n doubles,
 // what the reference's global FF would hold), B_out (n) and writes QuadTreeNode::radiosityValue; returns n or -1.
 int ref_adapter_radiosity(void *h, const double *light_center, uint32_t samples, uint32_t light_samples, uint64_t seed,

@@ -40,6 +40,7 @@ extern vector<ObjectNode *> radObjectNodes;      // radiosity.cpp:8
 
 // implemented in ref_driver_raster.cpp (that TU includes the reference's rasterizer.cpp)
 extern "C" void ref_raster_details_impl(Scene *scene, Camera *cam, double *out18);
+extern "C" int ref_raster_frame(Scene *scene, Camera *cam, int mode, const char *workdir, unsigned char *pixels);
 
 namespace {
 
@@ -354,6 +355,17 @@ void ref_set_materials(void *h, const double *mats) {
 		mat->Phong_exp = m[15]; mat->ref_index = m[16]; mat->microFacetsRoughness = m[17];
 		o->material = mat;
 	}
+}
+// camera of a scene built from arrays; then the reference's own raster loops (ref_driver_raster.cpp)
+void ref_set_camera14(void *h, const double *c14, uint32_t x_res, uint32_t y_res) {
+	Camera &cam = ((RefScene *)h)->cam;
+	cam.eye = V(c14); cam.lookat = V(c14 + 3); cam.up = V(c14 + 6);
+	cam.vpdist = c14[9]; cam.x_win.min = c14[10]; cam.x_win.max = c14[11]; cam.y_win.min = c14[12]; cam.y_win.max = c14[13];
+	cam.x_res = x_res; cam.y_res = y_res;
+}
+int ref_raster(void *h, int mode, const char *workdir, unsigned char *pixels) {
+	RefScene *s = (RefScene *)h;
+	return ref_raster_frame(&s->scene, &s->cam, mode, workdir, pixels);
 }
 void ref_set_max_depth(void *h, unsigned d) { ((RefScene *)h)->scene.max_tree_depth = d; }
 

@@ -23,3 +23,30 @@ extern "C" void ref_tone_map(long n, const double *rgb, unsigned char *out) {
 		out[3 * k] = p.r; out[3 * k + 1] = p.g; out[3 * k + 2] = p.b;
 	}
 }
+
+// The reference's own Rasterizer::Normal_Raster / Anti_Aliasing / Depth_Of_Field_Effect (rasterizer.cpp:243-406) over
+// the 8 × 6 thread rectangles they are written for (x_res must divide by 8, y_res by 6), into a PPM_Image:
+// pixels = x_res·y_res·3 ToneMap bytes.  They also write <workdir>/<name>.ppm after every rectangle.  mode 0, 1, 2.
+extern "C" int ref_raster_frame(Scene *scene, Camera *cam, int mode, const char *workdir, unsigned char *pixels) {
+	if (cam->x_res % threadDivisionsInX || cam->y_res % threadDivisionsInY) return 1;
+	string name = string(workdir) + "/ref_raster_frame";
+	PPM_Image I(cam->x_res, cam->y_res);
+	RasterDetails rd(*scene, *cam, name, I);
+	Rasterizer r;
+	std::streambuf *o = std::cout.rdbuf(nullptr);
+	for (int i = 0; i < threadDivisionsInX; ++i)
+		for (int j = 0; j < threadDivisionsInY; ++j) {
+			if (mode == 0) r.Normal_Raster(rd, i, j);
+			else if (mode == 1) r.Anti_Aliasing(rd, i, j);
+			else r.Depth_Of_Field_Effect(rd, i, j);
+		}
+	std::cout.rdbuf(o);
+	std::cout.clear();
+	for (unsigned i = 0; i < cam->y_res; ++i)
+		for (unsigned j = 0; j < cam->x_res; ++j) {
+			const Pixel &p = I(i, j);
+			unsigned char *q = pixels + 3 * ((size_t)i * cam->x_res + j);
+			q[0] = p.r; q[1] = p.g; q[2] = p.b;
+		}
+	return 0;
+}

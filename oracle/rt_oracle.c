@@ -140,6 +140,43 @@ void rto_primary_dirs(const double *rd, long n, const uint32_t *pix, double *dir
 	}
 }
 
+/* The three pixel loops of the Rasterizer: S rays per listed pixel in the reference's loop order.
+ * mode 0: Serial_Normal_Raster rasterizer.cpp:230 (S = 1); 1: Anti_Aliasing :327-343 (S = 4); 2: Depth_Of_Field_Effect
+ * :378-395 (S = 49: DistLensDim 7, Lwidth 0.375, Lheight 0.3, :61-64, :71-72).  o, d: n·S × 3. */
+void rto_raster_rays(int mode, const double *c, uint32_t x_res, uint32_t y_res, long n, const uint32_t *pix, double *o,
+                     double *d) {
+	double rd[18];
+	rto_raster_details(c, x_res, y_res, rd);
+	const v3 eye = ld3(c), lookat = ld3(c + 3), U = ld3(rd + 3), R = ld3(rd + 6), O = ld3(rd + 9), dR = ld3(rd + 12), dU = ld3(rd + 15);
+	const double vpdist = c[9], xmin = c[10], ymax = c[13];
+	const int dim = 7, grad = dim / 2;
+	const v3 XG = divs(scl(0.375, R), (double)dim), YG = divs(scl(0.3, U), (double)dim);
+	for (long k = 0; k < n; ++k) {
+		const uint32_t i = pix[2 * k], j = pix[2 * k + 1];
+		if (mode == 1) {
+			long s = 0;
+			for (float fy = 1; fy < 4; fy += 2)
+				for (float fx = 1; fx < 4; fx += 2, ++s) {
+					st3(o + 3 * (4 * k + s), eye);
+					st3(d + 3 * (4 * k + s), unit(sub(add(O, scl(j + (fx * 0.25), dR)), scl(i + (fy * 0.25), dU))));
+				}
+		} else if (mode == 2) {
+			long s = 0;
+			for (int yL = grad; yL >= -grad; --yL)
+				for (int xL = -grad; xL <= grad; ++xL, ++s) {
+					const v3 lens = add(add(eye, scl((double)xL, XG)), scl((double)yL, YG));
+					const v3 GL = unit(sub(lookat, lens));
+					const v3 OL = add(add(scl(vpdist, GL), scl(xmin, R)), scl(ymax, U));
+					st3(o + 3 * (49 * k + s), lens);
+					st3(d + 3 * (49 * k + s), unit(sub(add(OL, scl(j + 0.5, dR)), scl(i + 0.5, dU))));
+				}
+		} else {
+			st3(o + 3 * k, eye);
+			st3(d + 3 * k, unit(sub(add(O, scl(j + 0.5, dR)), scl(i + 0.5, dU))));
+		}
+	}
+}
+
 /* object.cpp:23 */
 static inline v3 hit_point(v3 o, v3 d, v3 v1, v3 n) {
 	return add(o, divs(scl(dot(sub(v1, o), n), d), dot(n, d)));

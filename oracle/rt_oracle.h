@@ -51,6 +51,11 @@ void rto_raster_details(const double *cam14, uint32_t x_res, uint32_t y_res, dou
 /* rasterizer.cpp:230: dir(i,j) = Unit(O + (j+.5)dR − (i+.5)dU); pix = n × (row i, col j) */
 void rto_primary_dirs(const double *rd18, long n, const uint32_t *pix, double *dir);
 
+/* rasterizer.cpp:219-233 (mode 0, S = 1), :297-349 (mode 1 anti-aliasing, S = 4), :351-406 (mode 2 depth of field,
+ * S = 49): the S generation-1 rays of each listed pixel in the reference's loop order; o, d: n·S × 3 */
+void rto_raster_rays(int mode, const double *cam14, uint32_t x_res, uint32_t y_res, long n, const uint32_t *pix, double *o,
+                     double *d);
+
 /* object.cpp:23: point = o + (d·((v1−o)·n)) / (n·d) */
 void rto_hit_point(const double o[3], const double d[3], const double v1[3], const double nrm[3], double p[3]);
 

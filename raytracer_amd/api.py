@@ -52,6 +52,15 @@ class rtmi_solve_stats(C.Structure):
                 ("bytes_per_sweep", C.c_double)]
 
 
+class rtmi_raster(C.Structure):
+    _fields_ = [("mode", C.c_uint32), ("lens_dim", C.c_uint32), ("sx", C.c_double), ("sy", C.c_double),
+                ("lookat", C.c_double * 3), ("R", C.c_double * 3), ("U", C.c_double * 3), ("x_gradation", C.c_double * 3),
+                ("y_gradation", C.c_double * 3), ("vpdist", C.c_double), ("xmin", C.c_double), ("ymax", C.c_double)]
+
+
+RASTER_NORMAL, RASTER_ANTI_ALIASING, RASTER_DEPTH_OF_FIELD = 0, 1, 2
+
+
 class rtmi_trace_params(C.Structure):
     _fields_ = [("max_tree_depth", C.c_uint32), ("ao_rays", C.c_uint32), ("ao_radius", C.c_double), ("seed", C.c_uint64)]
 
@@ -70,6 +79,7 @@ SYMBOLS = [
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev",
     "rtmi_shader_create", "rtmi_shader_destroy", "rtmi_trace_dev", "rtmi_render_frame_dev", "rtmi_tone_map_dev",
+    "rtmi_raster_setup", "rtmi_render_frame_sampled_dev",
 ]
 
 
@@ -114,6 +124,9 @@ def _load():
     L.rtmi_render_frame_dev.argtypes = [vp, C.POINTER(rtmi_camera), dbl, dbl, u32, u32, u32, u32,
                                         C.POINTER(rtmi_trace_params), vp, vp, vp]
     L.rtmi_tone_map_dev.argtypes = [vp, u64, vp, vp]
+    L.rtmi_raster_setup.argtypes = [u32, vp, vp, vp, dbl, vp, vp, C.POINTER(rtmi_raster)]
+    L.rtmi_render_frame_sampled_dev.argtypes = [vp, C.POINTER(rtmi_camera), C.POINTER(rtmi_raster), u32, u32, u32, u32,
+                                                C.POINTER(rtmi_trace_params), vp, vp, vp]
     return L
 
 
@@ -165,6 +178,7 @@ class Camera:
         self.c = rtmi_camera()
         eye, lookat, up = (_np(v, np.float64, (3,)) for v in (eye, lookat, up))
         x_win = _np(x_win, np.float64, (2,)); y_win = _np(y_win, np.float64, (2,))
+        self._args = (eye, lookat, up, float(vpdist), x_win, y_win)
         _check(lib.rtmi_camera_setup(_ptr(eye), _ptr(lookat), _ptr(up), float(vpdist), _ptr(x_win), _ptr(y_win),
                                      int(x_res), int(y_res), C.byref(self.c)))
 
@@ -180,6 +194,13 @@ class Camera:
     @property
     def y_res(self):
         return self.c.y_res
+
+    def raster(self, mode):
+        """The RasterDetails fields (rasterizer.cpp:40-68) the Anti_Aliasing / Depth_Of_Field_Effect loops read."""
+        eye, lookat, up, vpdist, x_win, y_win = self._args
+        out = rtmi_raster()
+        _check(lib.rtmi_raster_setup(int(mode), _ptr(eye), _ptr(lookat), _ptr(up), vpdist, _ptr(x_win), _ptr(y_win), C.byref(out)))
+        return out
 
     def raster_details(self):
         """(O, dR, dU) as computed on the host side of the library."""
@@ -322,14 +343,23 @@ class Shader:
         torch.cuda.synchronize()
         return d_rgb.cpu().numpy()
 
-    def Rasterize(self, cam, sx=0.5, sy=0.5, tile=(0, 0), tile_first=0, tile_stride=1):
-        """Rasterizer::Rasterize: returns (rgb y_res x x_res x 3 doubles, pixels y_res x x_res x 3 uint8 = ToneMap)."""
+    def render_frame_sampled_dev(self, cam, raster, d_rgb, d_pixels, tile=(0, 0), tile_first=0, tile_stride=1, stream=0):
+        _check(lib.rtmi_render_frame_sampled_dev(self.handle, C.byref(cam.c), C.byref(raster), tile[0], tile[1], tile_first,
+                                                 tile_stride, C.byref(self.params), d_rgb, d_pixels, stream))
+
+    def Rasterize(self, cam, sx=0.5, sy=0.5, tile=(0, 0), tile_first=0, tile_stride=1, mode=RASTER_NORMAL):
+        """Rasterizer::Rasterize: returns (rgb y_res x x_res x 3 doubles, pixels y_res x x_res x 3 uint8 = ToneMap).
+        mode: RASTER_NORMAL (Serial_Normal_Raster), RASTER_ANTI_ALIASING (Anti_Aliasing), RASTER_DEPTH_OF_FIELD."""
         import torch
         n = cam.x_res * cam.y_res
         d_rgb = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
         d_pix = torch.zeros(n, 3, dtype=torch.uint8, device="cuda")
-        self.render_frame_dev(cam, d_rgb.data_ptr(), d_pix.data_ptr(), sx, sy, tile, tile_first, tile_stride,
-                              torch.cuda.current_stream().cuda_stream)
+        if mode != RASTER_NORMAL:
+            self.render_frame_sampled_dev(cam, cam.raster(mode), d_rgb.data_ptr(), d_pix.data_ptr(), tile, tile_first, tile_stride,
+                                          torch.cuda.current_stream().cuda_stream)
+        else:
+            self.render_frame_dev(cam, d_rgb.data_ptr(), d_pix.data_ptr(), sx, sy, tile, tile_first, tile_stride,
+                                  torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         return (d_rgb.cpu().numpy().reshape(cam.y_res, cam.x_res, 3), d_pix.cpu().numpy().reshape(cam.y_res, cam.x_res, 3))
 

@@ -14,6 +14,8 @@
 // frame is queued without the host ever waiting.  Work the reference does but whose result it never uses is skipped:
 // AO where the point is shadowed or the material's ambient is 0, the local colour of refracting materials, a reflected
 // ray whose weight is 0.
+#include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "rtmi_host.hpp"
@@ -126,21 +128,37 @@ __global__ void k_set_counts(uint32_t *counts, uint32_t n_counters, uint32_t n) 
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k < n_counters) counts[k] = k == 0 ? n : 0u;
 }
-__global__ void __launch_bounds__(256) k_frame_rays(rtmi_camera cam, double sx, double sy, FrameGrid g, uint64_t item0, uint64_t n,
-                             rtmi_ray *__restrict__ rays, uint64_t *__restrict__ root) {
+// Generation-1 rays of a frame.  Item = pixel item · S + sample; S = 1 (Serial_Normal_Raster, rasterizer.cpp:230),
+// 4 (Anti_Aliasing, :327-343) or lens_dim² (Depth_Of_Field_Effect, :378-395), samples in the reference's loop order.
+__global__ void __launch_bounds__(256) k_frame_rays(rtmi_camera cam, rtmi_raster ras, uint32_t S, FrameGrid g, uint64_t item0, uint64_t n,
+                                                    rtmi_ray *__restrict__ rays, uint64_t *__restrict__ root) {
 	RTMI_FOR_ITEMS(k, in, n) {
 		if (!in) continue;
 		uint32_t i, j;
-		rtmi_ray R;
-		if (frame_pixel(g, cam, item0 + k, i, j)) {
+		const uint64_t item = item0 + k;
+		const uint32_t s = (uint32_t)(item % S);
+		if (frame_pixel(g, cam, item / S, i, j)) {
 			const D3 O = ld(cam.O), dR = ld(cam.dR), dU = ld(cam.dU);
-			set_ray(R, ld(cam.eye), unit((O + (j + sx) * dR) - (i + sy) * dU), RTMI_INFINITY);
-			root[k] = (uint64_t)i * cam.x_res + j;
+			D3 org = ld(cam.eye), dir;
+			if (ras.mode == RTMI_RASTER_ANTI_ALIASING) {
+				const float fragmenty = (s >> 1) ? 3.f : 1.f, fragmentx = (s & 1u) ? 3.f : 1.f; // :327-329
+				dir = unit((O + ((j + (fragmentx * 0.25)) * dR)) - ((i + (fragmenty * 0.25)) * dU)); // :335
+			} else if (ras.mode == RTMI_RASTER_DEPTH_OF_FIELD) {
+				const int grad = (int)(ras.lens_dim / 2);                                     // :64
+				const int yLens = grad - (int)(s / ras.lens_dim), xLens = -grad + (int)(s % ras.lens_dim); // :378-380
+				org = (ld(cam.eye) + ((double)xLens * ld(ras.x_gradation))) + ((double)yLens * ld(ras.y_gradation)); // :383
+				const D3 GLens = unit(ld(ras.lookat) - org);                                   // :384
+				const D3 OL = ((ras.vpdist * GLens) + (ras.xmin * ld(ras.R))) + (ras.ymax * ld(ras.U)); // :385
+				dir = unit((OL + ((j + 0.5) * dR)) - ((i + 0.5) * dU));                       // :386-388
+			} else {
+				dir = unit((O + (j + ras.sx) * dR) - (i + ras.sy) * dU);
+			}
+			set_ray(rays[k], org, dir, RTMI_INFINITY);
+			root[k] = ((uint64_t)i * cam.x_res + j) * S + s;
 		} else {
-			inactive(R);
+			inactive(rays[k]);
 			root[k] = ~0ull;
 		}
-		rays[k] = R;
 	}
 }
 __global__ void k_batch_roots(uint64_t first, uint64_t n, uint64_t *__restrict__ root) {
@@ -408,6 +426,22 @@ __global__ void __launch_bounds__(256) k_emit(const Node *__restrict__ nodes, co
 		if (pixels) { pixels[3 * at] = tone(r); pixels[3 * at + 1] = tone(g); pixels[3 * at + 2] = tone(b); }
 	}
 }
+// A pixel's S samples are S consecutive slots: contributedColor += Trace(...) in sample order, then / S
+// (rasterizer.cpp:337,343 and :394,398), then ToneMap.
+__global__ void __launch_bounds__(256) k_emit_mean(const Node *__restrict__ nodes, const uint64_t *__restrict__ root, uint64_t n_pixels,
+                                                   uint32_t S, double *__restrict__ rgb, uint8_t *__restrict__ pixels) {
+	RTMI_FOR_ITEMS(p, in, n_pixels) {
+		if (!in) continue;
+		const uint64_t dst = root[p * S];
+		if (dst == ~0ull) continue;
+		D3 c = d3(0.0, 0.0, 0.0);
+		for (uint32_t s = 0; s < S; ++s) c = c + ld(nodes[p * S + s].c);
+		c = c / (double)S;
+		const uint64_t at = dst / S;
+		if (rgb) { rgb[3 * at] = c.x; rgb[3 * at + 1] = c.y; rgb[3 * at + 2] = c.z; }
+		if (pixels) { pixels[3 * at] = tone(c.x); pixels[3 * at + 1] = tone(c.y); pixels[3 * at + 2] = tone(c.z); }
+	}
+}
 __global__ void k_fill_colour(uint64_t n, double r, double g, double b, double *__restrict__ rgb) {
 	RTMI_FOR_ITEMS(k, in, n) {
 		if (in) { rgb[3 * k] = r; rgb[3 * k + 1] = g; rgb[3 * k + 2] = b; }
@@ -443,7 +477,7 @@ struct Chunk {
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Lays the chunk's buffers out in the shader's workspace, growing it if needed.  want = generation-1 rays the caller has.
-static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t spp, Chunk &c, const char *who) {
+static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t spp, Chunk &c, const char *who, uint32_t group = 1) {
 	c.levels = levels;
 	c.branch = sh->any_translucent ? 2u : 1u;
 	c.spp = (sh->any_ambient ? spp : 0u);
@@ -457,6 +491,7 @@ static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t 
 	cap = std::min<uint64_t>(cap, (want + 255) & ~(uint64_t)255);
 	if (smax * (double)cap * std::max(1u, c.spp) > 4.0e9) cap = std::max<uint64_t>(256, (uint64_t)(4.0e9 / (smax * std::max(1u, c.spp))) & ~(uint64_t)255);
 	if (smax * (double)cap * std::max(1u, c.spp) > 4.0e9) return fail(std::string(who) + ": ray tree too wide for one launch; lower max_tree_depth");
+	cap = std::max<uint64_t>(group, cap / group * group); // a pixel's samples stay in one chunk
 	c.cap = cap;
 	c.slots.assign(levels, 0);
 	size_t off = 0;
@@ -606,13 +641,19 @@ int rtmi_trace_dev(rtmi_shader *sh, const rtmi_ray *d_rays, uint64_t n, uint32_t
 	return launch_check(who);
 }
 
-int rtmi_render_frame_dev(rtmi_shader *sh, const rtmi_camera *cam, double sx, double sy, uint32_t tile_w, uint32_t tile_h,
-                          uint32_t tile_first, uint32_t tile_stride, const rtmi_trace_params *params, double *d_rgb,
-                          uint8_t *d_pixels, void *stream) {
-	const char *who = "rtmi_render_frame_dev";
+int rtmi_render_frame_sampled_dev(rtmi_shader *sh, const rtmi_camera *cam, const rtmi_raster *raster, uint32_t tile_w, uint32_t tile_h,
+                                  uint32_t tile_first, uint32_t tile_stride, const rtmi_trace_params *params, double *d_rgb,
+                                  uint8_t *d_pixels, void *stream) {
+	const char *who = "rtmi_render_frame_sampled_dev";
 	if (!sh) return fail(std::string(who) + ": shader is NULL");
 	if (check_scene(sh->scene, who) || check_params(params, who)) return -1;
-	if (!cam || (!d_rgb && !d_pixels)) return fail(std::string(who) + ": NULL argument");
+	if (!cam || !raster || (!d_rgb && !d_pixels)) return fail(std::string(who) + ": NULL argument");
+	uint32_t S = 1;
+	if (raster->mode == RTMI_RASTER_ANTI_ALIASING) S = 4;
+	else if (raster->mode == RTMI_RASTER_DEPTH_OF_FIELD) {
+		if (raster->lens_dim == 0 || raster->lens_dim > 64) return fail(std::string(who) + ": lens_dim must be 1..64");
+		S = raster->lens_dim * raster->lens_dim;
+	} else if (raster->mode != RTMI_RASTER_NORMAL) return fail(std::string(who) + ": unknown raster mode");
 	if (cam->x_res == 0 || cam->y_res == 0) return 0;
 	if (tile_w == 0 || tile_h == 0) { tile_w = cam->x_res; tile_h = cam->y_res; }
 	if (tile_stride == 0) return fail(std::string(who) + ": tile_stride must be >= 1");
@@ -621,19 +662,68 @@ int rtmi_render_frame_dev(rtmi_shader *sh, const rtmi_camera *cam, double sx, do
 	const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
 	if (tile_first >= n_tiles) return 0;
 	const uint64_t mine = (n_tiles - tile_first + tile_stride - 1) / tile_stride;
-	const uint64_t n = mine * tile_w * tile_h;
+	const uint64_t n = mine * tile_w * tile_h * S;
 	hipStream_t st = (hipStream_t)stream;
 	if (params->max_tree_depth == 0) return fail(std::string(who) + ": max_tree_depth must be >= 1 (primary rays are generation 1)");
 	const FrameGrid g = {tile_w, tile_h, tiles_x, tile_first, tile_stride};
 	Chunk c;
-	if (plan_chunk(sh, n, params->max_tree_depth, params->ao_rays, c, who)) return -1;
+	if (plan_chunk(sh, n, params->max_tree_depth, params->ao_rays, c, who, S)) return -1;
 	for (uint64_t at = 0; at < n; at += c.cap) {
 		const uint64_t m = std::min<uint64_t>(c.cap, n - at);
-		hipLaunchKernelGGL(k_frame_rays, grid_for(sh, m), dim3(256), 0, st, *cam, sx, sy, g, at, m, c.rays[0], c.root);
+		hipLaunchKernelGGL(k_frame_rays, grid_for(sh, m), dim3(256), 0, st, *cam, *raster, S, g, at, m, c.rays[0], c.root);
 		if (run_chunk(sh, c, m, *params, st, who)) return -1;
-		hipLaunchKernelGGL(k_emit, grid_for(sh, m), dim3(256), 0, st, c.nodes[0], c.root, m, (uint64_t)0, d_rgb, d_pixels);
+		if (S == 1) hipLaunchKernelGGL(k_emit, grid_for(sh, m), dim3(256), 0, st, c.nodes[0], c.root, m, (uint64_t)0, d_rgb, d_pixels);
+		else hipLaunchKernelGGL(k_emit_mean, grid_for(sh, m / S), dim3(256), 0, st, c.nodes[0], c.root, m / S, S, d_rgb, d_pixels);
 	}
 	return launch_check(who);
+}
+
+int rtmi_render_frame_dev(rtmi_shader *sh, const rtmi_camera *cam, double sx, double sy, uint32_t tile_w, uint32_t tile_h,
+                          uint32_t tile_first, uint32_t tile_stride, const rtmi_trace_params *params, double *d_rgb,
+                          uint8_t *d_pixels, void *stream) {
+	rtmi_raster ras;
+	std::memset(&ras, 0, sizeof ras);
+	ras.mode = RTMI_RASTER_NORMAL;
+	ras.sx = sx; ras.sy = sy;
+	return rtmi_render_frame_sampled_dev(sh, cam, &ras, tile_w, tile_h, tile_first, tile_stride, params, d_rgb, d_pixels, stream);
+}
+
+// RasterDetails' constructor (rasterizer.cpp:40-68) for the fields the sampled rasters read, with the reference's Vec3
+// operators restated on the host.
+int rtmi_raster_setup(uint32_t mode, const double eye[3], const double lookat[3], const double up[3], double vpdist,
+                      const double x_win[2], const double y_win[2], rtmi_raster *out) {
+	if (!eye || !lookat || !up || !x_win || !y_win || !out) return fail("rtmi_raster_setup: NULL argument");
+	if (mode > RTMI_RASTER_DEPTH_OF_FIELD) return fail("rtmi_raster_setup: unknown raster mode");
+	struct V { double x, y, z; };
+	auto sub = [](V a, V b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; };
+	auto scl = [](double s, V a) { return V{s * a.x, s * a.y, s * a.z}; };
+	auto dotp = [](V a, V b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); };
+	auto divs = [](V a, double c) { return V{a.x / c, a.y / c, a.z / c}; };
+	auto l2 = [](V a) { return a.x * a.x + a.y * a.y + a.z * a.z; };
+	auto cross = [](V a, V b) { return V{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+	auto unitv = [&](V a) { double d = l2(a); return d > 0.0 ? divs(a, std::sqrt(d)) : V{0, 0, 0}; };
+	const V E{eye[0], eye[1], eye[2]}, L{lookat[0], lookat[1], lookat[2]}, Up{up[0], up[1], up[2]};
+	const V G = unitv(sub(L, E));                 // :49
+	V upG = Up;                                   // vec3.h:70-75
+	{
+		const double x = l2(G);
+		if (x > 0.0) upG = sub(Up, scl(dotp(Up, G) / x, G));
+	}
+	const V U = unitv(upG), R = unitv(cross(G, U)); // :50-51
+	std::memset(out, 0, sizeof *out);
+	out->mode = mode;
+	out->lens_dim = 7;                            // DistLensDim, :61
+	out->sx = out->sy = 0.5;
+	const V XG = divs(scl(0.375, R), 7.0), YG = divs(scl(0.3, U), 7.0); // Lwidth, Lheight :71-72, :62-63
+	out->lookat[0] = L.x; out->lookat[1] = L.y; out->lookat[2] = L.z;
+	out->R[0] = R.x; out->R[1] = R.y; out->R[2] = R.z;
+	out->U[0] = U.x; out->U[1] = U.y; out->U[2] = U.z;
+	out->x_gradation[0] = XG.x; out->x_gradation[1] = XG.y; out->x_gradation[2] = XG.z;
+	out->y_gradation[0] = YG.x; out->y_gradation[1] = YG.y; out->y_gradation[2] = YG.z;
+	out->vpdist = vpdist;
+	out->xmin = x_win[0];                         // :42
+	out->ymax = y_win[1];                         // :43
+	return 0;
 }
 
 int rtmi_tone_map_dev(const double *d_rgb, uint64_t n, uint8_t *d_pixels, void *stream) {

@@ -153,7 +153,7 @@ def test_adapter_rasterize_beside_the_references_trace(ref, oracle, tmp_path):
     else:
         pytest.skip("the reference's BSP build kept throwing")
     ref.set_materials(h, g["mats"])
-    ref.lib.ref_set_camera(h, _p(np.ascontiguousarray(g["cam14"])), C.c_uint32(int(g["res"][0])), C.c_uint32(int(g["res"][1])))
+    ref.set_camera(h, g["cam14"], g["res"])
     b = C.c_void_p(ref.lib.ref_adapter_bind(h))
     assert b, ref.lib.ref_adapter_error()
     o, d, _ = frame_rays(oracle, g["cam14"], g["res"])
@@ -166,7 +166,7 @@ def test_adapter_rasterize_beside_the_references_trace(ref, oracle, tmp_path):
     s = load_golden("g6_shade_studio.npz")
     h2 = ref.scene_one_tri_objects(s["tris"], s["normals"], s["tri_obj"], s["mats"], s["lights"])
     ref.set_max_depth(h2, 3)
-    ref.lib.ref_set_camera(h2, _p(np.ascontiguousarray(s["cam14"])), C.c_uint32(int(s["res"][0])), C.c_uint32(int(s["res"][1])))
+    ref.set_camera(h2, s["cam14"], s["res"])
     b2 = C.c_void_p(ref.lib.ref_adapter_bind(h2))
     assert b2, ref.lib.ref_adapter_error()
     o, d, _ = frame_rays(oracle, s["cam14"], s["res"])

@@ -120,6 +120,32 @@ def test_test1_frame_as_shipped(rt, oracle):
     assert dpx.max() <= int(256 * 0.85 * 0.1) + 1
 
 
+@pytest.mark.parametrize("name,mode", [("aa", 1), ("dof", 2)])
+def test_sampled_raster_loops(rt, oracle, name, mode):
+    """Anti_Aliasing / Depth_Of_Field_Effect on the device: colours against the oracle's restated loops (same sample
+    order, same mean), bytes against the reference's own Rasterizer functions (golden), and in two tile halves"""
+    g = load_golden("g6_shade_studio.npz")
+    r = load_golden("g6_raster_studio.npz")
+    res = r["res_" + name]
+    depth = int(r["depth_" + name])
+    scene, sh = _shader(rt, g, max_tree_depth=depth, ao_rays=10)
+    cam = rt.Camera.from_cam14(g["cam14"], res)
+    rgb, pix = sh.Rasterize(cam, mode=mode)
+    pl = np.array([(i, j) for i in range(int(res[1])) for j in range(int(res[0]))], np.uint32)
+    o, d, S = oracle.raster_rays(mode, g["cam14"], res, pl)
+    c = oracle.trace(g["tris"], g["normals"], g["tri_obj"], g["mats"], g["lights"], o, d, max_depth=depth, ao_rays=10).reshape(len(pl), S, 3)
+    acc = np.zeros((len(pl), 3))
+    for s in range(S):
+        acc = acc + c[:, s]
+    acc = acc / float(S)
+    assert np.abs(rgb.reshape(-1, 3) - acc).max() < TOL
+    edge = (np.abs(256 * acc - np.round(256 * acc)) < 256 * TOL).reshape(pix.shape)
+    assert not ((pix != r["pixels_" + name]) & ~edge).any()
+    a, _ = sh.Rasterize(cam, mode=mode, tile=(16, 12), tile_first=0, tile_stride=2)
+    b, _ = sh.Rasterize(cam, mode=mode, tile=(16, 12), tile_first=1, tile_stride=2)
+    assert np.array_equal(np.where(a != 0, a, b), rgb)
+
+
 def test_shader_errors(rt):
     g = load_golden("g6_shade_studio.npz")
     scene = rt.Scene(g["tris"], g["tri_obj"])

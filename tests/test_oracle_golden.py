@@ -239,3 +239,22 @@ def test_g6_shade_test1_as_shipped(oracle):
     assert kk.min() > -0.5 and kk.max() < 10.5
     assert np.abs(occ1[~lit] - g["rgb_sub"][~lit]).max() < 1e-9
     assert np.array_equal(oracle.tone_map(g["rgb_sub"]), g["pixels"][sub])
+
+
+@pytest.mark.parametrize("name,mode", [("aa", 1), ("dof", 2)])
+def test_g6_raster_loops_match_the_references(oracle, name, mode):
+    """Rasterizer::Anti_Aliasing (4 rays per pixel, depth 3) and Depth_Of_Field_Effect (49 lens rays per pixel) as the
+    reference itself runs them on the studio scene: the restated ray generators + Trace + mean + ToneMap give the same
+    bytes."""
+    g = load_golden("g6_shade_studio.npz")
+    r = load_golden("g6_raster_studio.npz")
+    res = r["res_" + name]
+    pix = np.array([(i, j) for i in range(int(res[1])) for j in range(int(res[0]))], np.uint32)
+    o, d, S = oracle.raster_rays(mode, g["cam14"], res, pix)
+    c = oracle.trace(g["tris"], g["normals"], g["tri_obj"], g["mats"], g["lights"], o, d, max_depth=int(r["depth_" + name]),
+                     ao_rays=10).reshape(len(pix), S, 3)
+    acc = np.zeros((len(pix), 3))
+    for s in range(S):
+        acc = acc + c[:, s]
+    acc = acc / float(S)
+    assert np.array_equal(oracle.tone_map(acc).reshape(r["pixels_" + name].shape), r["pixels_" + name])
