@@ -140,6 +140,15 @@ int rtmi_shadow_rays_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *
 int rtmi_ao_rays_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
                      uint32_t spp, double radius, uint64_t seed, rtmi_ray *d_out, void *stream);
 int rtmi_occlusion_fraction_dev(const uint8_t *d_occluded, uint64_t n, uint32_t spp, double *d_out, void *stream);
+/*   rtmi_soft_shadow_rays_dev    Shader::generateSoftShadows (Render2/shader.cpp:41-103; the shipped Shade has its call
+ *                          commented out, :475,521): n_points (reference: 100 = a 25 × 4 grid, :55-71) rays per hit toward
+ *                          the grid through the light centre, origin P + 0.05·direction; ask rtmi_closest_hit_dev, then
+ *   rtmi_soft_shadow_factor_dev  1 − contributors/n_points per hit, a ray contributing iff it hits a triangle of ANOTHER
+ *                          object than the shaded one (:93-100); the colour is multiplied by it */
+int rtmi_soft_shadow_rays_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                              const double light_center[3], uint32_t n_points, rtmi_ray *d_out, void *stream);
+int rtmi_soft_shadow_factor_dev(const rtmi_hit *d_hits, const rtmi_hit *d_shadow_hits, uint64_t n, uint32_t n_points,
+                                double *d_out, void *stream);
 
 /* ---- frame: Scene::Trace + Shader::Shade as a wavefront -------------------------------------------------
  * Replaces the recursion Scene::Trace (Render2/scene.cpp:127-155) -> Shader::Shade (Render2/shader.cpp:395-645, the

@@ -10,6 +10,8 @@ Shader::Shade (scene.cpp:127-155, shader.cpp:395-645), before ToneMap, plus its 
                         reference's random k; the tests solve for k and require an integer in 0..10.
   g6_raster_studio.npz  the same studio scene (ambient 0) through the reference's own Rasterizer::Anti_Aliasing (80x60,
                         depth 3) and Rasterizer::Depth_Of_Field_Effect (48x36, depth 1): ToneMap bytes.
+  g6_soft_shadow_studio.npz  Shader::generateSoftShadows (shader.cpp:41-103) called directly at every 7th hit point of the
+                        studio frame: the factor it multiplies the colour by.
   g6_shade_test1.npz    scenes/test1 exactly as main.cpp renders it (BSP built by the reference, ambient 0.1, AO 10 rays):
                         all 200 000 ToneMap'ed pixels + colours of every 16th pixel.
 
@@ -68,6 +70,20 @@ for name, mode, res, depth in (("aa", 1, (80, 60), 3), ("dof", 2, (48, 36), 1)):
     print("studio %s %dx%d depth %d: the reference's raster loop done" % (name, res[0], res[1], depth))
 np.savez_compressed(os.path.join(GOLD, "g6_raster_studio.npz"), **ras)
 shutil.rmtree(work2, ignore_errors=True)
+
+# ---- Shader::generateSoftShadows (uncalled by the shipped Shade; deterministic 25 x 4 grid) on the studio scene ----------
+# one-triangle Objects: "another object" (shader.cpp:93) = another triangle, and Scene::Cast is exact
+d_all = ora.primary_dirs(ora.raster_details(W.STUDIO_CAM14, XR, YR), np.array([(i, j) for i in range(YR) for j in range(XR)], np.uint32))
+o_all = np.tile(W.STUDIO_CAM14[:3], (len(d_all), 1))
+tri, t_, _, _ = ora.closest_hit(verts, o_all, d_all)
+sel = np.where(tri >= 0)[0][::7]
+Pss = ora.hit_point(o_all[sel], d_all[sel], verts[tri[sel], 0:3], nrm[tri[sel]])
+fac = ref.soft_shadow(h, Pss, tri[sel])
+so, sd = ora.soft_shadow_rays(Pss, lights[0, :3], 100)
+stri = ora.closest_hit(verts, so, sd)[0].reshape(len(sel), 100)
+mine = 1.0 - ((stri >= 0) & (stri != tri[sel][:, None])).sum(1) / 100.0
+print("soft shadows at %d points: reference factor mean %.3f, restatement differs at %d" % (len(sel), fac.mean(), (mine != fac).sum()))
+np.savez_compressed(os.path.join(GOLD, "g6_soft_shadow_studio.npz"), ray_index=sel, tri=tri[sel], P=Pss, factor=fac)
 
 # ---- test1 as shipped ------------------------------------------------------------------------------------
 work = tempfile.mkdtemp()

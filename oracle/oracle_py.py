@@ -101,6 +101,12 @@ class Oracle:
         self.lib.rto_shadow_rays(C.c_long(len(P)), _p(P), _p(N), _p(Cc), _p(o), _p(d))
         return o, d
 
+    def soft_shadow_rays(self, P, Cc, n_points=100):
+        P = _f64(P, (-1, 3)); Cc = _f64(Cc)
+        o = np.zeros((len(P) * n_points, 3)); d = np.zeros((len(P) * n_points, 3))
+        self.lib.rto_soft_shadow_rays(C.c_long(len(P)), _p(P), _p(Cc), C.c_uint32(n_points), _p(o), _p(d))
+        return o, d
+
     def ao_rays(self, P, N, R, spp, seed):
         P = _f64(P, (-1, 3)); N = _f64(N, (-1, 3))
         n = len(P)
@@ -359,6 +365,14 @@ class Reference:
         P = _f64(P, (-1, 3)); N = _f64(N, (-1, 3))
         out = np.zeros(len(P))
         self.lib.ref_ao_occlusion(h, C.c_long(len(P)), _p(P), _p(N), C.c_double(radius), C.c_int(nrays), _p(out))
+        return out
+
+    def soft_shadow(self, h, P, obj_index):
+        """Shader::generateSoftShadows at n surface points whose hit.object is sceneObjects[obj_index[k]] -> the factor
+        the reference multiplies the colour by"""
+        P = _f64(P, (-1, 3)); oi = np.ascontiguousarray(obj_index, np.int32)
+        out = np.zeros(len(P))
+        self.lib.ref_soft_shadow(h, C.c_long(len(P)), _p(P), _p(oi), _p(out))
         return out
 
     def brute(self, h, o, d):

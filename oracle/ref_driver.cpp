@@ -243,6 +243,20 @@ void ref_ao_occlusion(void *h, long n, const double *P, const double *N, double 
 	}
 }
 
+// Shader::generateSoftShadows (shader.cpp:41-103) at n surface points: hit.point = P[k], hit.object = sceneObjects[obj[k]];
+// colour White in -> out[k] = the factor 1 − contributors/100 (:100).  Needs a light and a built scene.
+void ref_soft_shadow(void *h, long n, const double *P, const int32_t *obj, double *out) {
+	RefScene *s = (RefScene *)h;
+	Shader sh;
+	for (long k = 0; k < n; ++k) {
+		HitInfo hit;
+		hit.point = V(P + 3 * k);
+		hit.object = s->scene.sceneObjects[obj[k]];
+		Color c = White;
+		out[k] = sh.generateSoftShadows(s->scene, hit, c).red;
+	}
+}
+
 // Brute force with the reference's triangle_intersection over the ORIGINAL triangles in
 // flattened order, keeping the strict minimum of the positive t (first wins on ties) —
 // the semantics of intersectTreeTraversalNoAccel (object.cpp:143-168) + Scene::Cast's

@@ -194,6 +194,24 @@ void rto_shadow_rays(long n, const double *P, const double *N, const double C[3]
 	}
 }
 
+/* shader.cpp:41-103 generateSoftShadows: n_points rays per point toward the grid through the light centre (:60-71),
+ * origin P + 0.05·dir (:90-91); ray k·n_points + i·divY + j */
+void rto_soft_shadow_rays(long n, const double *P, const double C[3], uint32_t n_points, double *o, double *d) {
+	uint32_t div_x = n_points, div_y = 1;
+	while (div_x % 2 == 0) { div_x /= 2; div_y *= 2; }
+	for (long k = 0; k < n; ++k) {
+		v3 p = ld3(P + 3 * k);
+		for (uint32_t i = 0; i < div_x; ++i)
+			for (uint32_t j = 0; j < div_y; ++j) {
+				v3 target = {C[0] - 1 + ((j * 2 + 1) / (double)div_y), C[1] - 1 + ((i * 2 + 1) / (double)div_x), C[2]};
+				v3 dir = unit(sub(target, p));
+				long at = k * (long)n_points + (long)i * div_y + j;
+				st3(d + 3 * at, dir);
+				st3(o + 3 * at, add(p, scl(0.05, dir)));
+			}
+	}
+}
+
 static inline uint64_t mix64(uint64_t z);
 /* shader.cpp:140-232 findOcclusionNew: the hemisphere frame and the AO ray of one square point (a, b) in
  * [-1,1)^2 (the reference draws a, b from an unseeded mt19937, :148-150,177; here they are injected).

@@ -62,6 +62,11 @@ void rto_hit_point(const double o[3], const double d[3], const double v1[3], con
 /* shader.cpp:116-127: shadow ray origin P + 0.01·n, direction Unit(C − P) */
 void rto_shadow_rays(long n, const double *P, const double *N, const double C[3], double *o, double *d);
 
+/* shader.cpp:41-103 (generateSoftShadows, uncalled by the shipped Shade): n_points (reference 100 -> 25 × 4 grid) rays per
+ * point toward the grid on the plane z = C.z, origin P + 0.05·dir.  The caller asks for the CLOSEST hit and counts the
+ * rays whose hit belongs to another object than the shaded point's (:93); factor = 1 − count/n_points. */
+void rto_soft_shadow_rays(long n, const double *P, const double C[3], uint32_t n_points, double *o, double *d);
+
 /* shader.cpp:140-232 (findOcclusionNew): spp AO rays per point; ray k·spp+s uses the square point
  * rto_ao_square_point(seed, k, s) where the reference draws from an unseeded mt19937.  Origin P + 1e-4·dir;
  * the caller asks "hit closer than R" (shader.cpp:226). */

@@ -79,7 +79,7 @@ SYMBOLS = [
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev",
     "rtmi_shader_create", "rtmi_shader_destroy", "rtmi_trace_dev", "rtmi_render_frame_dev", "rtmi_tone_map_dev",
-    "rtmi_raster_setup", "rtmi_render_frame_sampled_dev",
+    "rtmi_raster_setup", "rtmi_render_frame_sampled_dev", "rtmi_soft_shadow_rays_dev", "rtmi_soft_shadow_factor_dev",
 ]
 
 
@@ -107,6 +107,8 @@ def _load():
     L.rtmi_shadow_rays_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
     L.rtmi_ao_rays_dev.argtypes = [vp, vp, vp, vp, u64, u32, dbl, u64, vp, vp]
     L.rtmi_occlusion_fraction_dev.argtypes = [vp, u64, u32, vp, vp]
+    L.rtmi_soft_shadow_rays_dev.argtypes = [vp, vp, vp, vp, u64, vp, u32, vp, vp]
+    L.rtmi_soft_shadow_factor_dev.argtypes = [vp, vp, u64, u32, vp, vp]
     L.rtmi_patches_create.restype = vp
     L.rtmi_patches_create.argtypes = [vp, vp, vp]
     L.rtmi_patches_destroy.argtypes = [vp]
@@ -279,6 +281,11 @@ class Scene:
         """Shader::findOcclusionNew's rays (shader.cpp:140-232), spp per hit record."""
         _check(lib.rtmi_ao_rays_dev(self.handle, d_normals, d_rays, d_hits, n, spp, float(radius), seed, d_out, stream))
 
+    def soft_shadow_rays_dev(self, d_normals, d_rays, d_hits, n, light_center, n_points, d_out, stream=0):
+        """Shader::generateSoftShadows' rays (shader.cpp:41-103), n_points per hit record (reference: 100)."""
+        lc = _np(light_center, np.float64, (3,))
+        _check(lib.rtmi_soft_shadow_rays_dev(self.handle, d_normals, d_rays, d_hits, n, _ptr(lc), n_points, d_out, stream))
+
     def primary_work_dev(self, cam, d_counts, sx=0.5, sy=0.5, stream=0):
         """Diagnostic: adds (node visits, triangle tests) of the frame's primary rays to d_counts[0..1] (uint64)."""
         _check(lib.rtmi_primary_work_dev(self.handle, C.byref(cam.c), sx, sy, d_counts, stream))
@@ -287,6 +294,11 @@ class Scene:
 def occlusion_fraction_dev(d_occluded, n, spp, d_out, stream=0):
     """1 − occlusions/spp per hit (shader.cpp:231)."""
     _check(lib.rtmi_occlusion_fraction_dev(d_occluded, n, spp, d_out, stream))
+
+
+def soft_shadow_factor_dev(d_hits, d_shadow_hits, n, n_points, d_out, stream=0):
+    """1 − contributors/n_points per hit (shader.cpp:93-100)."""
+    _check(lib.rtmi_soft_shadow_factor_dev(d_hits, d_shadow_hits, n, n_points, d_out, stream))
 
 
 def primary_rays_dev(cam, d_rays, sx=0.5, sy=0.5, stream=0):

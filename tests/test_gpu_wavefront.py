@@ -126,3 +126,36 @@ def test_ao_fraction_vs_the_references_findOcclusionNew(rt):
     mine, ref = frac.cpu().numpy(), a["ref_ao"]
     se = np.sqrt(np.maximum(ref * (1 - ref), 1e-4) / NR) * np.sqrt(2.0)
     assert np.all(np.abs(mine - ref) <= 5 * se + 2e-3), np.abs(mine - ref).max()
+
+
+def test_soft_shadow_wavefront_studio(rt, oracle):
+    """primary hits -> 100 soft-shadow rays per hit generated on the device -> closest hit -> factor; against the oracle's
+    restated rays (every double) and the compiled reference's own Shader::generateSoftShadows (golden)"""
+    import torch
+    g = load_golden("g6_shade_studio.npz")
+    s = load_golden("g6_soft_shadow_studio.npz")
+    n_tris = len(g["tris"])
+    scene = rt.Scene(g["tris"], np.arange(n_tris, dtype=np.uint32))      # one object per triangle, as the golden scene
+    cam = rt.Camera.from_cam14(g["cam14"], g["res"])
+    n = cam.x_res * cam.y_res
+    st = torch.cuda.current_stream().cuda_stream
+    rays = torch.zeros(n * 64, dtype=torch.uint8, device="cuda"); hits = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+    nrm = torch.from_numpy(np.ascontiguousarray(g["normals"])).cuda()
+    rt.primary_rays_dev(cam, rays.data_ptr(), stream=st)
+    scene.cast_dev(rays.data_ptr(), n, hits.data_ptr(), stream=st)
+    NP = 100
+    srays = torch.zeros(n * NP * 64, dtype=torch.uint8, device="cuda"); shits = torch.zeros(n * NP * 24, dtype=torch.uint8, device="cuda")
+    fac = torch.zeros(n, dtype=torch.float64, device="cuda")
+    scene.soft_shadow_rays_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, g["lights"][0, :3], NP, srays.data_ptr(), st)
+    scene.cast_dev(srays.data_ptr(), n * NP, shits.data_ptr(), stream=st)
+    rt.soft_shadow_factor_dev(hits.data_ptr(), shits.data_ptr(), n, NP, fac.data_ptr(), st)
+    torch.cuda.synchronize()
+    k = s["ray_index"]
+    h = hits.cpu().numpy().view(rt.HIT_DTYPE)
+    assert np.array_equal(h["tri"][k].astype(np.int64), s["tri"].astype(np.int64))
+    sr = srays.cpu().numpy().view(rt.RAY_DTYPE).reshape(n, NP)
+    so, sd = oracle.soft_shadow_rays(s["P"], g["lights"][0, :3], NP)
+    assert np.array_equal(sr["o"][k].reshape(-1, 3), so) and np.array_equal(sr["d"][k].reshape(-1, 3), sd)
+    assert np.array_equal(fac.cpu().numpy()[k], s["factor"])
+    miss = h["tri"] == rt.MISS
+    assert np.all(sr["reserved"][miss] != 0) and np.all(fac.cpu().numpy()[miss] == 1.0)

@@ -258,3 +258,15 @@ def test_g6_raster_loops_match_the_references(oracle, name, mode):
         acc = acc + c[:, s]
     acc = acc / float(S)
     assert np.array_equal(oracle.tone_map(acc).reshape(r["pixels_" + name].shape), r["pixels_" + name])
+
+
+def test_g6_soft_shadow_factor(oracle):
+    """Shader::generateSoftShadows (shader.cpp:41-103) called directly in the compiled reference: the restated 25 x 4 grid,
+    rays and count give the same factor at every point"""
+    g = load_golden("g6_shade_studio.npz")
+    s = load_golden("g6_soft_shadow_studio.npz")
+    so, sd = oracle.soft_shadow_rays(s["P"], g["lights"][0, :3], 100)
+    stri = oracle.closest_hit(g["tris"], so, sd)[0].reshape(len(s["P"]), 100)
+    mine = 1.0 - ((stri >= 0) & (stri != s["tri"][:, None])).sum(1) / 100.0
+    assert np.array_equal(mine, s["factor"])
+    assert 0.5 < s["factor"].mean() < 0.99 and (s["factor"] < 1).sum() > 100
