@@ -219,6 +219,20 @@ int rtmi_render_frame_sampled_dev(rtmi_shader *, const rtmi_camera *cam, const r
 /* ToneMap (Render2/rasterizer.cpp:79-88) on n colours -> 3n bytes */
 int rtmi_tone_map_dev(const double *d_rgb, uint64_t n, uint8_t *d_pixels, void *stream);
 
+/* ---- scene files (host only, no GPU) ------------------------------------------------------------------
+ * Replaces bool Scene::BuildScene(file, fileObj, camera) (Render2/scene.cpp:209-460) with ParamReader
+ * (Render2/params.cpp): reads <scenes_dir>/<stem>.sdf and the <object name>.obj files it names, and hands out exactly
+ * the arrays the entry points above take: triangles in sceneObjects / Object::triangles order (quads split as
+ * params.cpp:214-241), triNormal per triangle (params.cpp:188-235), one material per object, the lights whose emission
+ * is not black (scene.cpp:276) as Center(GetBox(light)) + emission, and the camera as rtmi_camera_setup's arguments
+ * (cam14 = eye, lookat, up, vpdist, x_win, y_win).  Any pointer of rtmi_scene_file_get may be NULL. */
+typedef struct rtmi_scene_file rtmi_scene_file;
+rtmi_scene_file *rtmi_scene_file_load(const char *scenes_dir, const char *stem);
+void rtmi_scene_file_free(rtmi_scene_file *);
+int rtmi_scene_file_info(const rtmi_scene_file *, uint64_t *n_tris, uint32_t *n_objects, uint32_t *n_lights);
+int rtmi_scene_file_get(const rtmi_scene_file *, double *tri_xyz, uint32_t *tri_object, double *tri_normals,
+                        rtmi_material *materials, rtmi_light *lights, double cam14[14], uint32_t res[2]);
+
 /* ---- radiosity: form factors ------------------------------------------------------------------------
  * The patches are the scene's triangles (elements = the leaves every visibility ray is tested
  * against, Render2/radiosity.cpp:137-163), so patch i = triangle i of the scene.  verts: n × 9 doubles,

@@ -80,6 +80,7 @@ SYMBOLS = [
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev",
     "rtmi_shader_create", "rtmi_shader_destroy", "rtmi_trace_dev", "rtmi_render_frame_dev", "rtmi_tone_map_dev",
     "rtmi_raster_setup", "rtmi_render_frame_sampled_dev", "rtmi_soft_shadow_rays_dev", "rtmi_soft_shadow_factor_dev",
+    "rtmi_scene_file_load", "rtmi_scene_file_free", "rtmi_scene_file_info", "rtmi_scene_file_get",
 ]
 
 
@@ -129,6 +130,12 @@ def _load():
     L.rtmi_raster_setup.argtypes = [u32, vp, vp, vp, dbl, vp, vp, C.POINTER(rtmi_raster)]
     L.rtmi_render_frame_sampled_dev.argtypes = [vp, C.POINTER(rtmi_camera), C.POINTER(rtmi_raster), u32, u32, u32, u32,
                                                 C.POINTER(rtmi_trace_params), vp, vp, vp]
+    L.rtmi_scene_file_load.restype = vp
+    L.rtmi_scene_file_load.argtypes = [C.c_char_p, C.c_char_p]
+    L.rtmi_scene_file_free.argtypes = [vp]
+    L.rtmi_scene_file_free.restype = None
+    L.rtmi_scene_file_info.argtypes = [vp, vp, vp, vp]
+    L.rtmi_scene_file_get.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     return L
 
 
@@ -171,6 +178,26 @@ def triangle_intersection(o, d, v0, v1, v2, u0=0.0, v0_=0.0):
     t = np.zeros(n); u = np.full(n, float(u0)); v = np.full(n, float(v0_))
     _check(lib.rtmi_triangle_intersection(n, _ptr(o), _ptr(d), _ptr(tri), _ptr(t), _ptr(u), _ptr(v)))
     return t, u, v
+
+
+def BuildScene(scenes_dir, stem):
+    """bool Scene::BuildScene(file, fileObj, camera) (scene.cpp:209-460): reads <scenes_dir>/<stem>.sdf and its .obj files
+    (host only).  Returns a dict: tris n x 9, tri_obj n, normals n x 3, mats n_obj x 18, lights n_l x 6, cam14, res."""
+    h = lib.rtmi_scene_file_load(str(scenes_dir).encode(), str(stem).encode())
+    if not h:
+        raise RtmiError(lib.rtmi_last_error().decode())
+    h = C.c_void_p(h)
+    try:
+        n, no, nl = C.c_uint64(), C.c_uint32(), C.c_uint32()
+        _check(lib.rtmi_scene_file_info(h, C.byref(n), C.byref(no), C.byref(nl)))
+        out = dict(tris=np.zeros((n.value, 9)), tri_obj=np.zeros(n.value, np.uint32), normals=np.zeros((n.value, 3)),
+                   mats=np.zeros((no.value, MATERIAL_DOUBLES)), lights=np.zeros((nl.value, LIGHT_DOUBLES)), cam14=np.zeros(14),
+                   res=np.zeros(2, np.uint32))
+        _check(lib.rtmi_scene_file_get(h, _ptr(out["tris"]), _ptr(out["tri_obj"]), _ptr(out["normals"]), _ptr(out["mats"]),
+                                       _ptr(out["lights"]), _ptr(out["cam14"]), _ptr(out["res"])))
+        return out
+    finally:
+        lib.rtmi_scene_file_free(h)
 
 
 class Camera:

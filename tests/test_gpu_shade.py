@@ -146,6 +146,24 @@ def test_sampled_raster_loops(rt, oracle, name, mode):
     assert np.array_equal(np.where(a != 0, a, b), rgb)
 
 
+def test_scene_files_to_image_like_main_cpp(rt, tmp_path):
+    """The reference's main.cpp end to end without the reference: BuildScene (rtmi_scene_file_load) -> BuildBSP ->
+    Rasterize -> PPM; the test1 image equals the one the compiled reference's own pipeline produced (golden)."""
+    import os
+    from conftest import GOLDEN
+    g = load_golden("g6_shade_test1.npz")
+    s = rt.BuildScene(os.path.join(GOLDEN, "scenes"), "test1")
+    scene = rt.Scene(s["tris"], s["tri_obj"])
+    sh = rt.Shader(scene, s["normals"], s["mats"], s["lights"], max_tree_depth=1, ao_rays=10)
+    cam = rt.Camera.from_cam14(s["cam14"], s["res"])
+    _, pix = sh.Rasterize(cam)
+    assert np.array_equal(pix.reshape(-1, 3), g["pixels"])
+    out = tmp_path / "test1.ppm"
+    rt.write_ppm(str(out), pix)
+    raw = out.read_bytes()
+    assert raw.startswith(b"P6\n500 400\n255\n") and len(raw) == 15 + 600000      # scenes/out.ppm of the reference: 600 015 bytes
+
+
 def test_shader_errors(rt):
     g = load_golden("g6_shade_studio.npz")
     scene = rt.Scene(g["tris"], g["tri_obj"])

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, load_golden
+from conftest import GOLDEN, ROOT, load_golden
 
 
 def header_symbols():
@@ -124,3 +124,34 @@ def test_sharded_solve_world2_gloo(tmp_path, oracle):
     assert np.linalg.norm(B0[:ne, 0] - Bd[:ne]) / np.linalg.norm(Bd[:ne]) < 1e-5
     assert np.linalg.norm(B0[:ne, 0] - g["B_ref"][:ne]) / np.linalg.norm(g["B_ref"][:ne]) < 1e-4
     assert B0[ne, 0] == 68500.0
+
+
+SCENE_STEMS = ["test1", "test2", "test5", "test6", "test7", "scene_room_bed_sample", "radiosity_test", "practice_room_enclosed"]
+
+
+@pytest.mark.parametrize("stem", SCENE_STEMS)
+def test_scene_file_reader_matches_the_references_buildscene(stem):
+    """rtmi_scene_file_load on the reference's own scene files (tests/golden/scenes, data copied by
+    oracle/gen_golden_scenes.py) against what the compiled reference's Scene::BuildScene made of them: every double equal"""
+    import raytracer_amd as rt
+    g = np.load(os.path.join(GOLDEN, "g7_scene_files.npz"))
+    s = rt.BuildScene(os.path.join(GOLDEN, "scenes"), stem)
+    for key in ("tris", "tri_obj", "normals", "mats", "lights", "cam14", "res"):
+        assert np.array_equal(s[key], g[stem + "/" + key]), key
+
+
+def test_scene_file_reader_errors(tmp_path):
+    import raytracer_amd as rt
+    with pytest.raises(rt.RtmiError, match="could not open"):
+        rt.BuildScene(str(tmp_path), "nothing_here")
+    (tmp_path / "a.sdf").write_text("quadlight (0,0,0) (1,0,0) (1,1,0) (0,1,0)\n")
+    with pytest.raises(rt.RtmiError, match="quadlight"):
+        rt.BuildScene(str(tmp_path), "a")
+    # an .obj whose first line does not name the object is ignored, as in the reference (scene.cpp:400-405)
+    (tmp_path / "b.sdf").write_text("eye (0, 0, 5)\nobject thing\nend\n")
+    (tmp_path / "thing.obj").write_text("o other\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    s = rt.BuildScene(str(tmp_path), "b")
+    assert len(s["tris"]) == 0 and len(s["mats"]) == 1 and s["cam14"][2] == 5.0 and tuple(s["res"]) == (400, 400)
+    (tmp_path / "thing.obj").write_text("o thing\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nf 1 2 4 3\nf 1 2 9\n")
+    with pytest.raises(rt.RtmiError, match="does not exist"):
+        rt.BuildScene(str(tmp_path), "b")
