@@ -88,6 +88,12 @@ def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("librtmi.so is not built: run `make -C raytracer_amd/csrc` (or __graft_entry__.build()). "
                           "There is no CPU fallback for this path.")
+    try:
+        # PyTorch-ROCm bundles its own HIP runtime under the same soname as /opt/rocm's, which librtmi.so links: the
+        # process must load torch's copy first, or torch later finds "No HIP GPUs" through the other one.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_double
     L.rtmi_last_error.restype = C.c_char_p
