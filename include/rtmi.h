@@ -295,6 +295,26 @@ int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t
                              uint32_t check_every, rtmi_exchange_fn exchange, void *user, rtmi_solve_stats *stats,
                              void *stream);
 
+/* ---- radiosity: display ------------------------------------------------------------------------------
+ * Replaces the pixel loop of Rasterizer::Radiosity_Raster (Render2/rasterizer.cpp:408-470):
+ * I(i,j) = ToneMapRadiosity(radiosityHelper->trace_ray(ray, elements)), with
+ *   Radiosity_Helper::trace_ray (Render2/radiosity_helper.cpp:318-365): every element is intersected on the whole LINE
+ *     of the ray (t of either sign), inside ⇔ u ≥ 0 ∧ v ≥ 0 ∧ u+v ≤ 1 from returnUVofTriangle's pseudo-inverse
+ *     (Render2/util.cpp:126-147, mat3x2.h:187-283, computed on the host at rtmi_patches_create), nearest |P − origin|
+ *     wins; no element -> Green (0,1,0), back face -> Black;
+ *   the barycentric half of returnQuadTreeColor (Render2/radiosity_helper.h:235-267): Σ_k Area-weight_k · radiosity at
+ *     triVert_k.  d_vertex_radiosity: n_patches × 3 doubles (device) — the value returnQuadTreeColor attaches to each
+ *     vertex (its shared-vertex averages over QuadTreeNode::nextAdj are the host's; the adapter reads them off the
+ *     reference by evaluating it at the vertices); for flat shading pass B[i] three times;
+ *   ToneMapRadiosity (Render2/rasterizer.cpp:90-109).
+ * The query is the reference's O(elements) loop per ray, tiled through LDS; rays and frame conventions as above. */
+int rtmi_radiosity_trace_dev(rtmi_patches *, const double *d_vertex_radiosity, const rtmi_ray *d_rays, uint64_t n,
+                             double *d_rgb, void *stream);
+int rtmi_radiosity_raster_dev(rtmi_patches *, const double *d_vertex_radiosity, const rtmi_camera *cam, double sx, double sy,
+                              uint32_t tile_w, uint32_t tile_h, uint32_t tile_first, uint32_t tile_stride, double *d_rgb,
+                              uint8_t *d_pixels, void *stream);
+int rtmi_tone_map_radiosity_dev(const double *d_rgb, uint64_t n, uint8_t *d_pixels, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

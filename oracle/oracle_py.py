@@ -217,6 +217,26 @@ class Oracle:
         self.lib.rto_tone_map(C.c_long(len(rgb)), _p(rgb), _p(out))
         return out
 
+    def radiosity_trace(self, verts, normals, vertex_rad, o, d):
+        verts = _f64(verts, (-1, 9)); normals = _f64(normals, (-1, 3)); vr = _f64(vertex_rad, (-1, 3))
+        o = _f64(o, (-1, 3)); d = _f64(d, (-1, 3))
+        rgb = np.zeros((len(o), 3))
+        self.lib.rto_radiosity_trace(C.c_long(len(verts)), _p(verts), _p(normals), _p(vr), C.c_long(len(o)), _p(o), _p(d), _p(rgb))
+        return rgb
+
+    def pinv(self, verts):
+        verts = _f64(verts, (-1, 9))
+        A = np.zeros((len(verts), 3)); B = np.zeros((len(verts), 3)); ok = np.zeros(len(verts), np.uint8)
+        for i in range(len(verts)):
+            ok[i] = self.lib.rto_pinv(_p(verts[i]), _p(A[i]), _p(B[i]))
+        return A, B, ok
+
+    def tone_map_radiosity(self, rgb):
+        rgb = _f64(rgb, (-1, 3))
+        out = np.zeros((len(rgb), 3), np.uint8)
+        self.lib.rto_tone_map_radiosity(C.c_long(len(rgb)), _p(rgb), _p(out))
+        return out
+
     def num_threads(self):
         return self.lib.rto_num_threads()
 
@@ -441,6 +461,27 @@ class Reference:
     def rad_scatter_B(self, h, n_el):
         out = np.zeros(n_el)
         self.lib.ref_rad_scatter_B(h, _p(out))
+        return out
+
+    def rad_set_element_radiosity(self, h, B):
+        self.lib.ref_rad_set_element_radiosity(h, _p(_f64(B)))
+
+    def rad_trace_ray(self, h, o, d):
+        """Radiosity_Helper::trace_ray per ray -> n x 3"""
+        o = _f64(o, (-1, 3)); d = _f64(d, (-1, 3))
+        rgb = np.zeros((len(o), 3))
+        self.lib.ref_rad_trace_ray(h, C.c_long(len(o)), _p(o), _p(d), _p(rgb))
+        return rgb
+
+    def rad_vertex_radiosity(self, h, n_el):
+        out = np.zeros((n_el, 3))
+        self.lib.ref_rad_vertex_radiosity(h, _p(out))
+        return out
+
+    def tone_map_radiosity(self, rgb):
+        rgb = _f64(rgb, (-1, 3))
+        out = np.zeros((len(rgb), 3), np.uint8)
+        self.lib.ref_tone_map_radiosity(C.c_long(len(rgb)), _p(rgb), _p(out))
         return out
 
     def rad_residual(self, h):

@@ -537,6 +537,37 @@ void ref_rad_scatter_B(void *h, double *out) {
 	for (size_t i = 0; i < s->elems.size(); ++i) out[i] = s->elems[i]->radiosityValue;
 }
 
+// ---- radiosity display path (Rasterizer::Radiosity_Raster, rasterizer.cpp:408-470)
+// QuadTreeNode::radiosityValue of every element (what setRadiosityForAllElements would write)
+void ref_rad_set_element_radiosity(void *h, const double *B) {
+	RefScene *s = (RefScene *)h;
+	for (size_t i = 0; i < s->elems.size(); ++i) s->elems[i]->radiosityValue = B[i];
+}
+// Radiosity_Helper::trace_ray (radiosity_helper.cpp:318-365) over the element list, as Radiosity_Raster calls it
+void ref_rad_trace_ray(void *h, long n, const double *o, const double *d, double *rgb) {
+	RefScene *s = (RefScene *)h;
+	Ray ray;
+	ray.type = generic_ray;
+	ray.generation = 1;
+	for (long k = 0; k < n; ++k) {
+		ray.origin = V(o + 3 * k);
+		ray.direction = V(d + 3 * k);
+		Color c = s->rad->radiosityHelper->trace_ray(ray, s->elems);
+		rgb[3 * k] = c.red; rgb[3 * k + 1] = c.green; rgb[3 * k + 2] = c.blue;
+	}
+}
+// returnQuadTreeColor (radiosity_helper.h:156-268) evaluated AT the three vertices of every element: there the
+// barycentric weights are exactly (1,0,0), (0,1,0), (0,0,1), so the result is the interpolated radiosity the reference
+// attaches to that vertex (shared-vertex averages over nextAdj) — out: n_elements × 3
+void ref_rad_vertex_radiosity(void *h, double *out) {
+	RefScene *s = (RefScene *)h;
+	for (size_t i = 0; i < s->elems.size(); ++i) {
+		QuadTreeNode *e = s->elems[i];
+		Vec3 v[3] = {e->triVert1, e->triVert2, e->triVert3};
+		for (int k = 0; k < 3; ++k) out[3 * i + k] = returnQuadTreeColor(v[k], e).red;
+	}
+}
+
 // residual the reference's stop test looks at (radiosity.cpp:469-481): max_i |Σ_j K_ij B_j − E_i|
 double ref_rad_residual(void *h) {
 	int n = ref_rad_n(h);

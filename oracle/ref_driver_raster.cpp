@@ -50,3 +50,11 @@ extern "C" int ref_raster_frame(Scene *scene, Camera *cam, int mode, const char 
 		}
 	return 0;
 }
+
+// ToneMapRadiosity (rasterizer.cpp:90-109, file-static) on n colours -> n × 3 bytes
+extern "C" void ref_tone_map_radiosity(long n, const double *rgb, unsigned char *out) {
+	for (long k = 0; k < n; ++k) {
+		Pixel p = ToneMapRadiosity(Color(rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]));
+		out[3 * k] = p.r; out[3 * k + 1] = p.g; out[3 * k + 2] = p.b;
+	}
+}

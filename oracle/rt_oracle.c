@@ -869,3 +869,114 @@ void rto_tone_map(long n, const double *rgb, uint8_t *out) {
 		out[k] = (uint8_t)(c >= 255 ? 255 : c);
 	}
 }
+
+/* ---- radiosity display path: Rasterizer::Radiosity_Raster (rasterizer.cpp:408-470) ------------------------- */
+/* calculatePseudoInverse (mat3x2.h:187-283) of the 3×2 matrix [v2−v1 | v3−v1] as returnUVofTriangle sets it up
+ * (util.cpp:126-136): rows A, B with u = A·(p−v1), v = B·(p−v1).  Returns 0 when the reference reports "not invertible". */
+int rto_pinv(const double t[9], double A[3], double B[3]) {
+	const double m00 = t[3] - t[0], m01 = t[6] - t[0], m10 = t[4] - t[1], m11 = t[7] - t[1], m20 = t[5] - t[2], m21 = t[8] - t[2];
+	const double x = m00 * m00 + m10 * m10 + m20 * m20;
+	const double z = m01 * m00 + m11 * m10 + m21 * m20;
+	const double y = m00 * m01 + m10 * m11 + m20 * m21;
+	const double w = m01 * m01 + m11 * m11 + m21 * m21;
+	double e1 = (x + w) + sqrt(pow((x + w), 2) - (4.0 * ((x * w) - (y * z))));
+	e1 /= 2.0;
+	double e2 = (x + w) - sqrt(pow((x + w), 2) - (4.0 * ((x * w) - (y * z))));
+	e2 /= 2.0;
+	if (e1 == 0.0 || e2 == 0.0) return 0;
+	if (e1 == e2) {
+		A[0] = m00 / e1; A[1] = m10 / e1; A[2] = m20 / e1;
+		B[0] = m01 / e1; B[1] = m11 / e1; B[2] = m21 / e1;
+		return 1;
+	}
+	if (z == 0.0 && y == 0.0) {
+		A[0] = m00 / e1; A[1] = m10 / e1; A[2] = m20 / e1;
+		if (fabs((A[0] * m00 + A[1] * m10 + A[2] * m20) - 1.0) > RTO_EPSILON) {
+			A[0] = m00 / e2; A[1] = m10 / e2; A[2] = m20 / e2;
+			B[0] = m01 / e1; B[1] = m11 / e1; B[2] = m21 / e1;
+			return 1;
+		}
+		B[0] = m01 / e2; B[1] = m11 / e2; B[2] = m21 / e2;
+		return 1;
+	}
+	const double l1x2 = fabs(x - e1), l1x1 = ((-1.0 * y) / (x - e1)) * l1x2;
+	const double l2x2 = fabs(x - e2), l2x1 = ((-1.0 * y) / (x - e2)) * l2x2;
+	double d1 = (l1x1 * l1x1) + (l1x2 * l1x2), d2 = (l2x1 * l2x1) + (l2x2 * l2x2);   /* vec2.h Unit */
+	const double v1x = d1 > 0.0 ? l1x1 / sqrt(d1) : 0, v1y = d1 > 0.0 ? l1x2 / sqrt(d1) : 0;
+	const double v2x = d2 > 0.0 ? l2x1 / sqrt(d2) : 0, v2y = d2 > 0.0 ? l2x2 / sqrt(d2) : 0;
+	v3 U1 = {m00 * v1x + m01 * v1y, m10 * v1x + m11 * v1y, m20 * v1x + m21 * v1y};
+	v3 U2 = {m00 * v2x + m01 * v2y, m10 * v2x + m11 * v2y, m20 * v2x + m21 * v2y};
+	U1 = unit(divs(U1, sqrt(e1)));
+	U2 = unit(divs(U2, sqrt(e2)));
+	const double i1x = v1x * (1.0 / sqrt(e1)), i1y = v2x * (1.0 / sqrt(e2));
+	const double i2x = v1y * (1.0 / sqrt(e1)), i2y = v2y * (1.0 / sqrt(e2));
+	A[0] = i1x * U1.x + i1y * U2.x; A[1] = i1x * U1.y + i1y * U2.y; A[2] = i1x * U1.z + i1y * U2.z;
+	B[0] = i2x * U1.x + i2y * U2.x; B[1] = i2x * U1.y + i2y * U2.y; B[2] = i2x * U1.z + i2y * U2.z;
+	return 1;
+}
+
+static double area3(v3 a, v3 b, v3 c) { return len(cross(sub(b, a), sub(c, a))) / 2.0; } /* vec3.h:116-118 */
+
+/* Radiosity_Helper::trace_ray (radiosity_helper.cpp:318-365) + returnQuadTreeColor (radiosity_helper.h:156-268) with the
+ * radiosity of each element's three vertices injected (vertex_rad n×3: what the first half of returnQuadTreeColor
+ * attaches to triVert1..3; equal to the element's radiosityValue where no shared-vertex average applies).
+ * Every element is tested on the whole LINE (t of either sign), inside ⇔ u ≥ 0 ∧ v ≥ 0 ∧ u+v ≤ 1 with (u,v) from the
+ * pseudo-inverse, the nearest |P − o| wins (first on ties; a distance of exactly 0 counts as "none yet", :342).
+ * No element → Green (0,1,0); back face (n·d > 0) → Black. */
+void rto_radiosity_trace(long n_el, const double *verts, const double *normals, const double *vertex_rad, long n_rays,
+                         const double *o, const double *d, double *rgb) {
+	double *A = (double *)malloc(sizeof(double) * 3 * (size_t)n_el), *B = (double *)malloc(sizeof(double) * 3 * (size_t)n_el);
+	int *inv = (int *)malloc(sizeof(int) * (size_t)n_el);
+	for (long i = 0; i < n_el; ++i) inv[i] = rto_pinv(verts + 9 * i, A + 3 * i, B + 3 * i);
+#pragma omp parallel for schedule(dynamic, 64)
+	for (long k = 0; k < n_rays; ++k) {
+		const v3 O = ld3(o + 3 * k), D = ld3(d + 3 * k);
+		double dist = 0.0;
+		long hit = -1;
+		v3 fp = {0, 0, 0};
+		for (long i = 0; i < n_el; ++i) {
+			const v3 n = ld3(normals + 3 * i), v1 = ld3(verts + 9 * i);
+			const double denom = dot(n, D);
+			if (denom != 0.0) {
+				const double t = -1.0 * ((dot(n, O) + dot(scl(-1.0, n), v1)) / denom);
+				const v3 P = add(scl(t, D), O);
+				double u = 0.0, v = 0.0;
+				if (inv[i]) {
+					const v3 q = sub(P, v1);
+					u = A[3 * i] * q.x + A[3 * i + 1] * q.y + A[3 * i + 2] * q.z;
+					v = B[3 * i] * q.x + B[3 * i + 1] * q.y + B[3 * i + 2] * q.z;
+				}
+				if (u >= 0.0 && v >= 0.0 && u + v <= 1.0) {
+					const double L = len(sub(P, O));
+					if (dist == 0.0 || dist > L) { fp = P; hit = i; dist = L; }
+				}
+			}
+		}
+		double c[3] = {0.0, 1.0, 0.0};                    /* Green */
+		if (hit >= 0) {
+			if (dot(ld3(normals + 3 * hit), D) > 0.0) c[0] = c[1] = c[2] = 0.0;
+			else {
+				const v3 a = ld3(verts + 9 * hit), b = ld3(verts + 9 * hit + 3), cc = ld3(verts + 9 * hit + 6);
+				const double ar = area3(a, b, cc);
+				const double w1 = area3(fp, b, cc) / ar, w2 = area3(fp, a, cc) / ar, w3 = area3(fp, a, b) / ar;
+				double f = 0.0;
+				f += (w1 * vertex_rad[3 * hit]);
+				f += (w2 * vertex_rad[3 * hit + 1]);
+				f += (w3 * vertex_rad[3 * hit + 2]);
+				c[0] = c[1] = c[2] = f;
+			}
+		}
+		rgb[3 * k] = c[0]; rgb[3 * k + 1] = c[1]; rgb[3 * k + 2] = c[2];
+	}
+	free(A); free(B); free(inv);
+}
+
+/* ToneMapRadiosity, rasterizer.cpp:90-109: Green -> (0,255,0); else every channel = (channel)(255 · red/(red+1)) */
+void rto_tone_map_radiosity(long n, const double *rgb, uint8_t *out) {
+	for (long k = 0; k < n; ++k) {
+		const double *c = rgb + 3 * k;
+		if (c[0] == 0.0 && c[1] == 1.0 && c[2] == 0.0) { out[3 * k] = 0; out[3 * k + 1] = 255; out[3 * k + 2] = 0; continue; }
+		const uint8_t g = (uint8_t)((double)255 * (c[0] / (c[0] + 1.0)));
+		out[3 * k] = out[3 * k + 1] = out[3 * k + 2] = g;
+	}
+}

@@ -152,6 +152,16 @@ void rto_trace(long n_tris, const double *tris, const double *normals, const uin
 /* rasterizer.cpp:79-88 */
 void rto_tone_map(long n, const double *rgb, uint8_t *out);
 
+/* ---- radiosity display path (Rasterizer::Radiosity_Raster, rasterizer.cpp:408-470) ----
+ * rto_pinv: calculatePseudoInverse (mat3x2.h:187-283) as returnUVofTriangle uses it (util.cpp:126-147).
+ * rto_radiosity_trace: Radiosity_Helper::trace_ray (radiosity_helper.cpp:318-365) + the barycentric half of
+ * returnQuadTreeColor (radiosity_helper.h:235-267) with per-vertex radiosities injected (vertex_rad n × 3).
+ * rto_tone_map_radiosity: ToneMapRadiosity (rasterizer.cpp:90-109). */
+int rto_pinv(const double tri9[9], double A[3], double B[3]);
+void rto_radiosity_trace(long n_el, const double *verts, const double *normals, const double *vertex_rad, long n_rays,
+                         const double *o, const double *d, double *rgb);
+void rto_tone_map_radiosity(long n, const double *rgb, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,7 @@ SYMBOLS = [
     "rtmi_shader_create", "rtmi_shader_destroy", "rtmi_trace_dev", "rtmi_render_frame_dev", "rtmi_tone_map_dev",
     "rtmi_raster_setup", "rtmi_render_frame_sampled_dev", "rtmi_soft_shadow_rays_dev", "rtmi_soft_shadow_factor_dev",
     "rtmi_scene_file_load", "rtmi_scene_file_free", "rtmi_scene_file_info", "rtmi_scene_file_get",
+    "rtmi_radiosity_trace_dev", "rtmi_radiosity_raster_dev", "rtmi_tone_map_radiosity_dev",
 ]
 
 
@@ -136,6 +137,9 @@ def _load():
     L.rtmi_raster_setup.argtypes = [u32, vp, vp, vp, dbl, vp, vp, C.POINTER(rtmi_raster)]
     L.rtmi_render_frame_sampled_dev.argtypes = [vp, C.POINTER(rtmi_camera), C.POINTER(rtmi_raster), u32, u32, u32, u32,
                                                 C.POINTER(rtmi_trace_params), vp, vp, vp]
+    L.rtmi_radiosity_trace_dev.argtypes = [vp, vp, vp, u64, vp, vp]
+    L.rtmi_radiosity_raster_dev.argtypes = [vp, vp, C.POINTER(rtmi_camera), dbl, dbl, u32, u32, u32, u32, vp, vp, vp]
+    L.rtmi_tone_map_radiosity_dev.argtypes = [vp, u64, vp, vp]
     L.rtmi_scene_file_load.restype = vp
     L.rtmi_scene_file_load.argtypes = [C.c_char_p, C.c_char_p]
     L.rtmi_scene_file_free.argtypes = [vp]
@@ -515,6 +519,41 @@ class Radiosity:
         """radiosity.cpp:122-134: QuadTreeNode::radiosityValue[i] = B[i] (monochrome = channel 0), as doubles."""
         self.radiosityValue = self.B[: self.numOfElements, 0].double().cpu().numpy()
         return self.radiosityValue
+
+    # -- display path (Rasterizer::Radiosity_Raster, rasterizer.cpp:408-470)
+    def _vertex_radiosity(self, vertex_radiosity):
+        import torch
+        if vertex_radiosity is None:      # flat: returnQuadTreeColor without shared-vertex averages = radiosityValue at every vertex
+            vertex_radiosity = np.repeat(np.asarray(self.radiosityValue, np.float64)[:, None], 3, 1)
+        vr = _np(vertex_radiosity, np.float64, (-1, 3))
+        if len(vr) != self.numOfElements:
+            raise ValueError("one row of three vertex radiosities per element")
+        return torch.from_numpy(vr.copy()).cuda()
+
+    def trace_ray(self, rays, vertex_radiosity=None):
+        """Radiosity_Helper::trace_ray (radiosity_helper.cpp:318-365) for a batch of RAY_DTYPE records -> n x 3 colours."""
+        import torch
+        rays = _np(rays, RAY_DTYPE)
+        n = len(rays)
+        d_vr = self._vertex_radiosity(vertex_radiosity)
+        d_rays = torch.from_numpy(rays.view(np.uint8).reshape(n, 64).copy()).cuda()
+        d_rgb = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+        _check(lib.rtmi_radiosity_trace_dev(self.handle, d_vr.data_ptr(), d_rays.data_ptr(), n, d_rgb.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return d_rgb.cpu().numpy()
+
+    def Radiosity_Raster(self, cam, vertex_radiosity=None, sx=0.5, sy=0.5, tile=(0, 0), tile_first=0, tile_stride=1):
+        """Rasterizer::Radiosity_Raster: (rgb y x x x 3 doubles, pixels y x x x 3 uint8 = ToneMapRadiosity)."""
+        import torch
+        n = cam.x_res * cam.y_res
+        d_vr = self._vertex_radiosity(vertex_radiosity)
+        d_rgb = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+        d_pix = torch.zeros(n, 3, dtype=torch.uint8, device="cuda")
+        _check(lib.rtmi_radiosity_raster_dev(self.handle, d_vr.data_ptr(), C.byref(cam.c), sx, sy, tile[0], tile[1], tile_first,
+                                             tile_stride, d_rgb.data_ptr(), d_pix.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return (d_rgb.cpu().numpy().reshape(cam.y_res, cam.x_res, 3), d_pix.cpu().numpy().reshape(cam.y_res, cam.x_res, 3))
 
 
 def jacobi_sweep_dev(d_F, ld, n, row0, n_rows, rho, d_E, d_B_old, d_B_new, d_norms, stream=0):

@@ -15,6 +15,7 @@ struct rtmi_patches {
 	double *d_verts;   // n × 9: v1, v2, v3 in ORIGINAL order (util.cpp:113-115 samples from these)
 	double *d_normals; // n × 3: triNormal
 	double *d_area;    // n: vec3.h:116-118
+	double *d_display; // n × 16 (display path): triNormal, triVert1, pseudo-inverse rows A, B (mat3x2.h:187-283), (−n)·v1, invertible, pad
 };
 
 namespace rtmi {
@@ -22,6 +23,11 @@ namespace rtmi {
 constexpr double kEpsilon = 1.0e-5;       // Render2/base.h:57
 constexpr double kPi = 3.14159265358979;  // Render2/base.h:52
 constexpr uint32_t kLightStream = 0xFFFFFFFFu;
+
+struct rtmi_patches_dev_view { // what the display kernels read
+	const double *verts, *normals, *display;
+	uint32_t n;
+};
 
 struct PatchesDev {
 	const double *verts, *normals, *area;
@@ -261,6 +267,179 @@ __global__ __launch_bounds__(kJBlock) void k_jacobi_sweep(const float *__restric
 	}
 }
 
+// ---------------------------------------------------------------- radiosity display path
+// Radiosity_Helper::trace_ray (radiosity_helper.cpp:318-365) + the barycentric half of returnQuadTreeColor
+// (radiosity_helper.h:235-267): one ray per thread against EVERY element (the reference's loop; elements are staged
+// through LDS in tiles, all lanes read the same record).  An element is tested on the whole line (t of either sign), inside
+// ⇔ u ≥ 0 ∧ v ≥ 0 ∧ u + v ≤ 1 with (u, v) = rows of the pseudo-inverse · (P − v1) (util.cpp:126-147); the nearest |P − o|
+// wins, first on ties, and a distance of exactly 0 counts as "nothing yet" (:342).  No element: Green; back face: Black.
+constexpr uint32_t kDispTile = 128, kDispRec = 16;
+struct DispRay { double ox, oy, oz, dx, dy, dz; bool active; };
+
+template <class Fetch, class Emit>
+__device__ __forceinline__ void display_trace(const rtmi_patches_dev_view P, const double *__restrict__ vertex_rad, uint64_t n_items,
+                                              Fetch fetch, Emit emit) {
+	__shared__ double tile[kDispTile * kDispRec];
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	DispRay r;
+	r.active = k < n_items && fetch(k, r);
+	const D3 O = d3(r.ox, r.oy, r.oz), D = d3(r.dx, r.dy, r.dz);
+	double dist = 0.0;
+	int hit = -1;
+	D3 fp = d3(0, 0, 0);
+	for (uint32_t base = 0; base < P.n; base += kDispTile) {
+		const uint32_t cnt = min(kDispTile, P.n - base);
+		__syncthreads();
+		for (uint32_t w = threadIdx.x; w < cnt * kDispRec; w += blockDim.x) tile[w] = P.display[(size_t)base * kDispRec + w];
+		__syncthreads();
+		if (!r.active) continue;
+		for (uint32_t e = 0; e < cnt; ++e) {
+			const double *t = tile + e * kDispRec;
+			const D3 n = d3(t[0], t[1], t[2]);
+			const double denom = dot(n, D);
+			if (denom != 0.0) {
+				const double tt = -1.0 * ((dot(n, O) + t[12]) / denom); // :332
+				const D3 Pt = (tt * D) + O;                             // :334
+				double u = 0.0, v = 0.0;
+				if (t[13] != 0.0) {
+					const D3 q = Pt - d3(t[3], t[4], t[5]);
+					u = t[6] * q.x + t[7] * q.y + t[8] * q.z;          // util.cpp:140-141
+					v = t[9] * q.x + t[10] * q.y + t[11] * q.z;
+				}
+				if (u >= 0.0 && v >= 0.0 && u + v <= 1.0) {
+					const double L = sqrt(len2(Pt - O));
+					if (dist == 0.0 || dist > L) { fp = Pt; hit = (int)(base + e); dist = L; }
+				}
+			}
+		}
+	}
+	if (!r.active) return;
+	D3 c = d3(0.0, 1.0, 0.0); // Green
+	if (hit >= 0) {
+		const double *nv = P.normals + 3 * (size_t)hit;
+		if (dot(d3(nv[0], nv[1], nv[2]), D) > 0.0) c = d3(0.0, 0.0, 0.0);
+		else {
+			const double *p = P.verts + 9 * (size_t)hit;
+			const D3 a = d3(p[0], p[1], p[2]), b = d3(p[3], p[4], p[5]), cc = d3(p[6], p[7], p[8]);
+			auto area = [](D3 A, D3 B, D3 C) { return sqrt(len2(cross(B - A, C - A))) / 2.0; }; // vec3.h:116-118
+			const double ar = area(a, b, cc);
+			const double w1 = area(fp, b, cc) / ar, w2 = area(fp, a, cc) / ar, w3 = area(fp, a, b) / ar; // radiosity_helper.h:235-238
+			double f = 0.0;
+			f += (w1 * vertex_rad[3 * (size_t)hit]);     // :250,256 in edge-list order: triVert1, 2, 3
+			f += (w2 * vertex_rad[3 * (size_t)hit + 1]);
+			f += (w3 * vertex_rad[3 * (size_t)hit + 2]);
+			c = d3(f, f, f);
+		}
+	}
+	emit(k, c);
+}
+
+// ToneMapRadiosity, rasterizer.cpp:90-109
+__device__ __forceinline__ void tone_radiosity(D3 c, uint8_t *px) {
+	if (c.x == 0.0 && c.y == 1.0 && c.z == 0.0) { px[0] = 0; px[1] = 255; px[2] = 0; return; }
+	const uint8_t g = (uint8_t)(int)((double)255 * (c.x / (c.x + 1.0)));
+	px[0] = px[1] = px[2] = g;
+}
+
+__global__ void __launch_bounds__(256) k_display_rays(rtmi_patches_dev_view P, const double *__restrict__ vertex_rad,
+                                                      const rtmi_ray *__restrict__ rays, uint64_t n, double *__restrict__ rgb) {
+	auto fetch = [&](uint64_t k, DispRay &r) {
+		const rtmi_ray &q = rays[k];
+		if (q.reserved != 0.0) return false;
+		r.ox = q.o[0]; r.oy = q.o[1]; r.oz = q.o[2]; r.dx = q.d[0]; r.dy = q.d[1]; r.dz = q.d[2];
+		return true;
+	};
+	auto emit = [&](uint64_t k, D3 c) { rgb[3 * k] = c.x; rgb[3 * k + 1] = c.y; rgb[3 * k + 2] = c.z; };
+	display_trace(P, vertex_rad, n, fetch, emit);
+}
+
+// the pixel loop of Rasterizer::Radiosity_Raster (rasterizer.cpp:436-455): items enumerate this rank's tiles
+__global__ void __launch_bounds__(256) k_display_frame(rtmi_patches_dev_view P, const double *__restrict__ vertex_rad, rtmi_camera cam,
+                                                       double sx, double sy, uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x,
+                                                       uint32_t tile_first, uint32_t tile_stride, uint64_t n_items,
+                                                       double *__restrict__ rgb, uint8_t *__restrict__ pixels) {
+	auto pixel = [&](uint64_t k, uint32_t &i, uint32_t &j) {
+		const uint32_t per = tile_w * tile_h, tile = tile_first + (uint32_t)(k / per) * tile_stride, in = (uint32_t)(k % per);
+		j = (tile % tiles_x) * tile_w + in % tile_w;
+		i = (tile / tiles_x) * tile_h + in / tile_w;
+		return j < cam.x_res && i < cam.y_res;
+	};
+	auto fetch = [&](uint64_t k, DispRay &r) {
+		uint32_t i, j;
+		if (!pixel(k, i, j)) return false;
+		const D3 O = d3(cam.O[0], cam.O[1], cam.O[2]), dR = d3(cam.dR[0], cam.dR[1], cam.dR[2]), dU = d3(cam.dU[0], cam.dU[1], cam.dU[2]);
+		const D3 d = unit((O + (j + sx) * dR) - (i + sy) * dU); // rasterizer.cpp:452
+		r.ox = cam.eye[0]; r.oy = cam.eye[1]; r.oz = cam.eye[2]; r.dx = d.x; r.dy = d.y; r.dz = d.z;
+		return true;
+	};
+	auto emit = [&](uint64_t k, D3 c) {
+		uint32_t i, j;
+		pixel(k, i, j);
+		const uint64_t at = (uint64_t)i * cam.x_res + j;
+		if (rgb) { rgb[3 * at] = c.x; rgb[3 * at + 1] = c.y; rgb[3 * at + 2] = c.z; }
+		if (pixels) tone_radiosity(c, pixels + 3 * at);
+	};
+	display_trace(P, vertex_rad, n_items, fetch, emit);
+}
+
+__global__ void k_tone_map_radiosity(const double *__restrict__ rgb, uint64_t n, uint8_t *__restrict__ pixels) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < n) tone_radiosity(d3(rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]), pixels + 3 * k);
+}
+
+// calculatePseudoInverse (Render2/mat3x2.h:187-283) of [v2−v1 | v3−v1] (util.cpp:128-134), host side, same libm calls;
+// rec = the 16-double display record of one element
+static void display_record(const double *t, const double *nrm, double *rec) {
+	for (int a = 0; a < 3; ++a) { rec[a] = nrm[a]; rec[3 + a] = t[a]; }
+	double *A = rec + 6, *B = rec + 9;
+	for (int a = 0; a < 6; ++a) A[a] = 0.0;
+	rec[12] = ((-1.0 * nrm[0]) * t[0]) + ((-1.0 * nrm[1]) * t[1]) + ((-1.0 * nrm[2]) * t[2]); // (−1.0·n)·v1, radiosity_helper.cpp:332
+	rec[13] = 0.0; rec[14] = rec[15] = 0.0;
+	const double m00 = t[3] - t[0], m01 = t[6] - t[0], m10 = t[4] - t[1], m11 = t[7] - t[1], m20 = t[5] - t[2], m21 = t[8] - t[2];
+	const double x = m00 * m00 + m10 * m10 + m20 * m20;
+	const double z = m01 * m00 + m11 * m10 + m21 * m20;
+	const double y = m00 * m01 + m10 * m11 + m20 * m21;
+	const double w = m01 * m01 + m11 * m11 + m21 * m21;
+	double e1 = (x + w) + std::sqrt(std::pow((x + w), 2) - (4.0 * ((x * w) - (y * z))));
+	e1 /= 2.0;
+	double e2 = (x + w) - std::sqrt(std::pow((x + w), 2) - (4.0 * ((x * w) - (y * z))));
+	e2 /= 2.0;
+	if (e1 == 0.0 || e2 == 0.0) return; // "not an invertable matrix": returnUVofTriangle then answers (0, 0)
+	rec[13] = 1.0;
+	if (e1 == e2) {
+		A[0] = m00 / e1; A[1] = m10 / e1; A[2] = m20 / e1;
+		B[0] = m01 / e1; B[1] = m11 / e1; B[2] = m21 / e1;
+		return;
+	}
+	if (z == 0.0 && y == 0.0) {
+		A[0] = m00 / e1; A[1] = m10 / e1; A[2] = m20 / e1;
+		if (std::fabs((A[0] * m00 + A[1] * m10 + A[2] * m20) - 1.0) > kEpsilon) {
+			A[0] = m00 / e2; A[1] = m10 / e2; A[2] = m20 / e2;
+			B[0] = m01 / e1; B[1] = m11 / e1; B[2] = m21 / e1;
+			return;
+		}
+		B[0] = m01 / e2; B[1] = m11 / e2; B[2] = m21 / e2;
+		return;
+	}
+	const double l1x2 = std::fabs(x - e1), l1x1 = ((-1.0 * y) / (x - e1)) * l1x2;
+	const double l2x2 = std::fabs(x - e2), l2x1 = ((-1.0 * y) / (x - e2)) * l2x2;
+	const double d1 = (l1x1 * l1x1) + (l1x2 * l1x2), d2 = (l2x1 * l2x1) + (l2x2 * l2x2); // vec2.h:100-104
+	const double v1x = d1 > 0.0 ? l1x1 / std::sqrt(d1) : 0, v1y = d1 > 0.0 ? l1x2 / std::sqrt(d1) : 0;
+	const double v2x = d2 > 0.0 ? l2x1 / std::sqrt(d2) : 0, v2y = d2 > 0.0 ? l2x2 / std::sqrt(d2) : 0;
+	double U1[3] = {m00 * v1x + m01 * v1y, m10 * v1x + m11 * v1y, m20 * v1x + m21 * v1y};
+	double U2[3] = {m00 * v2x + m01 * v2y, m10 * v2x + m11 * v2y, m20 * v2x + m21 * v2y};
+	auto unit3 = [](double *u) {
+		const double dd = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+		if (dd > 0.0) { const double s = std::sqrt(dd); u[0] /= s; u[1] /= s; u[2] /= s; }
+		else u[0] = u[1] = u[2] = 0.0;
+	};
+	for (int a = 0; a < 3; ++a) { U1[a] = U1[a] / std::sqrt(e1); U2[a] = U2[a] / std::sqrt(e2); }
+	unit3(U1); unit3(U2);
+	const double i1x = v1x * (1.0 / std::sqrt(e1)), i1y = v2x * (1.0 / std::sqrt(e2));
+	const double i2x = v1y * (1.0 / std::sqrt(e1)), i2y = v2y * (1.0 / std::sqrt(e2));
+	for (int a = 0; a < 3; ++a) { A[a] = i1x * U1[a] + i1y * U2[a]; B[a] = i2x * U1[a] + i2y * U2[a]; }
+}
+
 static int check_patches(const rtmi_patches *p, const char *who) {
 	if (!p) return fail(std::string(who) + ": patches is NULL");
 	int dev = -1;
@@ -296,13 +475,17 @@ rtmi_patches *rtmi_patches_create(rtmi_scene *s, const double *verts, const doub
 		const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
 		area[i] = std::sqrt(cx * cx + cy * cy + cz * cz) / 2.0;
 	}
+	std::vector<double> disp((size_t)n * kDispRec);
+	for (uint32_t i = 0; i < n; ++i) display_record(verts + 9 * (size_t)i, normals + 3 * (size_t)i, disp.data() + (size_t)i * kDispRec);
 	rtmi_patches *P = new rtmi_patches();
 	P->scene = s;
 	P->n = n;
-	P->d_verts = P->d_normals = P->d_area = nullptr;
+	P->d_verts = P->d_normals = P->d_area = P->d_display = nullptr;
 	bool ok = hipMalloc(&P->d_verts, sizeof(double) * 9 * (size_t)n) == hipSuccess &&
 	          hipMalloc(&P->d_normals, sizeof(double) * 3 * (size_t)n) == hipSuccess &&
-	          hipMalloc(&P->d_area, sizeof(double) * (size_t)n) == hipSuccess;
+	          hipMalloc(&P->d_area, sizeof(double) * (size_t)n) == hipSuccess &&
+	          hipMalloc(&P->d_display, sizeof(double) * kDispRec * (size_t)n) == hipSuccess;
+	ok = ok && hipMemcpy(P->d_display, disp.data(), sizeof(double) * kDispRec * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(P->d_verts, verts, sizeof(double) * 9 * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(P->d_normals, normals, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(P->d_area, area.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
@@ -319,6 +502,7 @@ void rtmi_patches_destroy(rtmi_patches *P) {
 	if (P->d_verts) (void)hipFree(P->d_verts);
 	if (P->d_normals) (void)hipFree(P->d_normals);
 	if (P->d_area) (void)hipFree(P->d_area);
+	if (P->d_display) (void)hipFree(P->d_display);
 	delete P;
 }
 
@@ -449,6 +633,47 @@ int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t
 	if (d_tmp) (void)hipFree(d_tmp);
 	if (d_norms) (void)hipFree(d_norms);
 	return rc;
+}
+
+int rtmi_radiosity_trace_dev(rtmi_patches *P, const double *d_vertex_radiosity, const rtmi_ray *d_rays, uint64_t n, double *d_rgb,
+                             void *stream) {
+	const char *who = "rtmi_radiosity_trace_dev";
+	if (check_patches(P, who)) return -1;
+	if (n == 0) return 0;
+	if (!d_vertex_radiosity || !d_rays || !d_rgb) return fail(std::string(who) + ": NULL argument");
+	if (n > (uint64_t)0x7fffffff * 256) return fail(std::string(who) + ": too many rays for one launch");
+	const rtmi_patches_dev_view V = {P->d_verts, P->d_normals, P->d_display, P->n};
+	hipLaunchKernelGGL(k_display_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, V, d_vertex_radiosity, d_rays, n, d_rgb);
+	return launch_check(who);
+}
+
+int rtmi_radiosity_raster_dev(rtmi_patches *P, const double *d_vertex_radiosity, const rtmi_camera *cam, double sx, double sy,
+                              uint32_t tile_w, uint32_t tile_h, uint32_t tile_first, uint32_t tile_stride, double *d_rgb,
+                              uint8_t *d_pixels, void *stream) {
+	const char *who = "rtmi_radiosity_raster_dev";
+	if (check_patches(P, who)) return -1;
+	if (!d_vertex_radiosity || !cam || (!d_rgb && !d_pixels)) return fail(std::string(who) + ": NULL argument");
+	if (cam->x_res == 0 || cam->y_res == 0) return 0;
+	if (tile_w == 0 || tile_h == 0) { tile_w = cam->x_res; tile_h = cam->y_res; }
+	if (tile_stride == 0) return fail(std::string(who) + ": tile_stride must be >= 1");
+	if ((uint64_t)tile_w * tile_h > 0x7fffffffull) return fail(std::string(who) + ": tile too large");
+	const uint32_t tiles_x = (cam->x_res + tile_w - 1) / tile_w, tiles_y = (cam->y_res + tile_h - 1) / tile_h;
+	const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
+	if (tile_first >= n_tiles) return 0;
+	const uint64_t n = ((n_tiles - tile_first + tile_stride - 1) / tile_stride) * tile_w * tile_h;
+	if (n > (uint64_t)0x7fffffff * 256) return fail(std::string(who) + ": frame too large for one launch");
+	const rtmi_patches_dev_view V = {P->d_verts, P->d_normals, P->d_display, P->n};
+	hipLaunchKernelGGL(k_display_frame, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, V, d_vertex_radiosity, *cam, sx, sy,
+	                   tile_w, tile_h, tiles_x, tile_first, tile_stride, n, d_rgb, d_pixels);
+	return launch_check(who);
+}
+
+int rtmi_tone_map_radiosity_dev(const double *d_rgb, uint64_t n, uint8_t *d_pixels, void *stream) {
+	const char *who = "rtmi_tone_map_radiosity_dev";
+	if (n == 0) return 0;
+	if (!d_rgb || !d_pixels) return fail(std::string(who) + ": NULL argument");
+	hipLaunchKernelGGL(k_tone_map_radiosity, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_rgb, n, d_pixels);
+	return launch_check(who);
 }
 
 } // extern "C"

@@ -44,7 +44,7 @@ V3 unit(V3 a) { // vec3.h:98
 }
 
 struct Col { double r = 0, g = 0, b = 0; };
-const Col kWhite = {1.0, 1.0, 1.0}, kBlack = {0.0, 0.0, 0.0};
+const Col kWhite = {1.0, 1.0, 1.0};
 struct Mat { Col diffuse, specular, emission, ambient, reflectivity, translucency; double rough = 0, phong = 0, ref_index = 0; };
 
 // Render2/params.cpp, function by function

@@ -308,3 +308,33 @@ def test_jacobi_argument_errors(rt):
         rt.jacobi_sweep_dev(x.data_ptr(), 4, 3, 2, 3, rho, x.data_ptr(), x.data_ptr(), x.data_ptr() + 16, x.data_ptr(), 0)  # rows > n
     with pytest.raises(rt.RtmiError):
         rt.jacobi_sweep_dev(x.data_ptr(), 4, 3, 0, 3, rho, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 0)       # in place
+
+
+@pytest.mark.parametrize("stem", ["radiosity_test", "practice_room_enclosed"])
+def test_radiosity_display_path(rt, oracle, stem):
+    """rtmi_radiosity_trace_dev / rtmi_radiosity_raster_dev against the compiled reference's trace_ray + ToneMapRadiosity
+    (golden, every 4th pixel) and against the oracle on the whole frame: no transcendental on the device, so bit-exact"""
+    g = load_golden("g8_radiosity_display.npz")
+    G = lambda k: g[stem + "/" + k]
+    scene = rt.Scene(G("verts"))
+    rad = rt.Radiosity(scene, G("normals"))
+    rad.radiosityValue = G("B")
+    cam = rt.Camera.from_cam14(G("cam14"), G("res"))
+    rgb, pix = rad.Radiosity_Raster(cam, G("vertex_rad"))
+    k = G("pix")[:, 0].astype(np.int64), G("pix")[:, 1].astype(np.int64)
+    assert np.array_equal(rgb[k], G("rgb"))
+    assert np.array_equal(pix[k], G("pixels"))
+    # whole frame vs the oracle, and the batch entry point on the same rays
+    allpix = np.array([(i, j) for i in range(cam.y_res) for j in range(cam.x_res)], np.uint32)
+    d = oracle.primary_dirs(oracle.raster_details(G("cam14"), G("res")[0], G("res")[1]), allpix)
+    o = np.tile(G("cam14")[:3], (len(d), 1))
+    want = oracle.radiosity_trace(G("verts"), G("normals"), G("vertex_rad"), o, d)
+    assert np.array_equal(rgb.reshape(-1, 3), want)
+    assert np.array_equal(pix.reshape(-1, 3), oracle.tone_map_radiosity(want))
+    assert np.array_equal(rad.trace_ray(rt.make_rays(o[::3], d[::3]), G("vertex_rad")), want[::3])
+    # tiles of two ranks; flat shading = vertex radiosity B, B, B
+    a, _ = rad.Radiosity_Raster(cam, G("vertex_rad"), tile=(50, 40), tile_first=0, tile_stride=2)
+    b, _ = rad.Radiosity_Raster(cam, G("vertex_rad"), tile=(50, 40), tile_first=1, tile_stride=2)
+    assert np.array_equal(np.where(a != 0, a, b), rgb)
+    flat, _ = rad.Radiosity_Raster(cam)
+    assert np.array_equal(flat.reshape(-1, 3), oracle.radiosity_trace(G("verts"), G("normals"), np.repeat(G("B")[:, None], 3, 1), o, d))

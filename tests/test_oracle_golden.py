@@ -270,3 +270,19 @@ def test_g6_soft_shadow_factor(oracle):
     mine = 1.0 - ((stri >= 0) & (stri != s["tri"][:, None])).sum(1) / 100.0
     assert np.array_equal(mine, s["factor"])
     assert 0.5 < s["factor"].mean() < 0.99 and (s["factor"] < 1).sum() > 100
+
+
+@pytest.mark.parametrize("stem", ["radiosity_test", "practice_room_enclosed"])
+def test_g8_radiosity_display_path(oracle, stem):
+    """Radiosity_Helper::trace_ray + returnQuadTreeColor + ToneMapRadiosity (the body of Rasterizer::Radiosity_Raster's
+    pixel loop) as the compiled reference computed them: the restatement is equal to the bit"""
+    g = load_golden("g8_radiosity_display.npz")
+    G = lambda k: g[stem + "/" + k]
+    d = oracle.primary_dirs(oracle.raster_details(G("cam14"), G("res")[0], G("res")[1]), G("pix"))
+    o = np.tile(G("cam14")[:3], (len(d), 1))
+    rgb = oracle.radiosity_trace(G("verts"), G("normals"), G("vertex_rad"), o, d)
+    assert np.array_equal(rgb, G("rgb"))
+    assert np.array_equal(oracle.tone_map_radiosity(rgb), G("pixels"))
+    # the fixture has all three outcomes: no element (Green), back face (Black, radiosity_test only), shaded
+    green = (rgb == [0, 1, 0]).all(1)
+    assert green.any() and (~green & (rgb[:, 0] > 0)).sum() > 1000
