@@ -12,7 +12,8 @@
 //   rtmi_host::ShaderBinding  Scene::Trace + Shader::Shade (scene.cpp:127-155, shader.cpp:395-645) and the pixel loop of
 //                             Rasterizer::Serial_Normal_Raster (rasterizer.cpp:191-241)            -> Trace(), Rasterize()
 //   rtmi_host::RadiosityBinding  findFormFactor / progressiveRefinement / setRadiosityForAllElements
-//                             (radiosity.cpp:335-467, 483-563, 122-134) on the element list
+//                             (radiosity.cpp:335-467, 483-563, 122-134) on the element list; Radiosity_Raster
+//                             (rasterizer.cpp:408-470) into the reference's PPM_Image
 #ifndef RTMI_ADAPTER_HPP
 #define RTMI_ADAPTER_HPP
 #include <hip/hip_runtime_api.h>
@@ -309,6 +310,48 @@ public:
 	// Radiosity::setRadiosityForAllElements (radiosity.cpp:122-134)
 	void setRadiosityForAllElements() {
 		for (size_t i = 0; i < elems_.size(); ++i) elems_[i]->radiosityValue = B_[i];
+	}
+
+	// The pixel loop of Rasterizer::Radiosity_Raster (rasterizer.cpp:436-455):
+	// I(i, j) = ToneMapRadiosity(radiosityHelper->trace_ray(ray(i, j), elements)).  The shared-vertex averages of
+	// returnQuadTreeColor (radiosity_helper.h:156-213, over QuadTreeNode::nextAdj) stay the reference's: its own function is
+	// evaluated at the three vertices of every element, where its barycentric weights are exactly (1,0,0), (0,1,0),
+	// (0,0,1) — found at instantiation, so the host must have included radiosity_helper.h.  Reads radiosityValue.
+	template <class CameraT, class ImageT>
+	void Radiosity_Raster(const CameraT &cam, ImageT &I) const {
+		const size_t ne = elems_.size();
+		std::vector<double> vr(3 * ne);
+		for (size_t i = 0; i < ne; ++i) {
+			auto v1 = elems_[i]->triVert1, v2 = elems_[i]->triVert2, v3 = elems_[i]->triVert3;
+			vr[3 * i] = returnQuadTreeColor(v1, elems_[i]).red;
+			vr[3 * i + 1] = returnQuadTreeColor(v2, elems_[i]).red;
+			vr[3 * i + 2] = returnQuadTreeColor(v3, elems_[i]).red;
+		}
+		rtmi_camera c;
+		double eye[3], lookat[3], up[3];
+		put3(eye, cam.eye); put3(lookat, cam.lookat); put3(up, cam.up);
+		const double xw[2] = {cam.x_win.min, cam.x_win.max}, yw[2] = {cam.y_win.min, cam.y_win.max};
+		if (rtmi_camera_setup(eye, lookat, up, cam.vpdist, xw, yw, cam.x_res, cam.y_res, &c) != 0) throw Error("rtmi_camera_setup");
+		const size_t n = (size_t)cam.x_res * cam.y_res;
+		double *d_vr = nullptr;
+		uint8_t *d_pix = nullptr;
+		if (hipMalloc((void **)&d_vr, sizeof(double) * 3 * ne) != hipSuccess || hipMalloc((void **)&d_pix, 3 * n) != hipSuccess) {
+			if (d_vr) (void)hipFree(d_vr);
+			throw std::runtime_error("hipMalloc failed");
+		}
+		std::vector<uint8_t> px(3 * n);
+		bool ok = hipMemcpy(d_vr, vr.data(), sizeof(double) * 3 * ne, hipMemcpyHostToDevice) == hipSuccess;
+		const int rc = ok ? rtmi_radiosity_raster_dev(patches_, d_vr, &c, 0.5, 0.5, 0, 0, 0, 1, nullptr, d_pix, nullptr) : -1;
+		ok = ok && rc == 0 && hipMemcpy(px.data(), d_pix, 3 * n, hipMemcpyDeviceToHost) == hipSuccess;
+		(void)hipFree(d_vr);
+		(void)hipFree(d_pix);
+		if (!ok) throw Error("rtmi_radiosity_raster_dev");
+		for (unsigned i = 0; i < cam.y_res; ++i)
+			for (unsigned j = 0; j < cam.x_res; ++j) {
+				const uint8_t *p = &px[3 * ((size_t)i * cam.x_res + j)];
+				auto &dst = I(i, j);
+				dst.r = p[0]; dst.g = p[1]; dst.b = p[2];
+			}
 	}
 
 private:

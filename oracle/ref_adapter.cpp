@@ -160,4 +160,25 @@ int ref_adapter_radiosity(void *h, const double *light_center, uint32_t samples,
 	}
 }
 
+// Rasterizer::Radiosity_Raster's pixel loop through the adapter, on the reference's element list (needs ref_rad_setup)
+// with whatever QuadTreeNode::radiosityValue holds: pixels = x_res·y_res·3 ToneMapRadiosity bytes.
+int ref_adapter_radiosity_raster(void *h, uint8_t *pixels) {
+	RefScene *s = (RefScene *)h;
+	try {
+		RadBinding rb;
+		if (!rb.setElements(s->elems, nullptr)) return -1;
+		PPM_Image I(s->cam.x_res, s->cam.y_res);
+		rb.Radiosity_Raster(s->cam, I);
+		for (unsigned i = 0; i < s->cam.y_res; ++i)
+			for (unsigned j = 0; j < s->cam.x_res; ++j) {
+				const Pixel &p = I(i, j);
+				uint8_t *q = pixels + 3 * ((size_t)i * s->cam.x_res + j);
+				q[0] = p.r; q[1] = p.g; q[2] = p.b;
+			}
+		return 0;
+	} catch (const std::exception &) {
+		return -1;
+	}
+}
+
 } // extern "C"

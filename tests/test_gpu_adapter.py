@@ -175,3 +175,31 @@ def test_adapter_rasterize_beside_the_references_trace(ref, oracle, tmp_path):
     wp = ref.tone_map(s["rgb_d3"])
     edge = np.abs(256 * s["rgb_d3"] - np.round(256 * s["rgb_d3"])) < 1e-8
     assert not ((px2.reshape(-1, 3) != wp) & ~edge).any()
+
+
+def test_adapter_radiosity_raster_beside_the_references_trace_ray(ref, oracle, tmp_path):
+    """rtmi_host::RadiosityBinding::Radiosity_Raster on the reference's own QuadTreeNode list, Camera and PPM_Image beside
+    its own ToneMapRadiosity(trace_ray(ray)) loop (rasterizer.cpp:436-455): the same bytes on every pixel"""
+    from conftest import frame_rays
+    g = load_golden("g8_radiosity_display.npz")
+    gs = np.load(os.path.join(ROOT, "tests", "golden", "g7_scene_files.npz"))
+    stem = "practice_room_enclosed"
+    tris, tobj = gs[stem + "/tris"], gs[stem + "/tri_obj"]
+    h = None
+    for _ in range(10):
+        h = ref.scene_from_triangles(tris, tobj, gs[stem + "/lights"][0, :3])
+        if ref.build_bsp(h, str(tmp_path)) == 0:
+            break
+    else:
+        pytest.skip("the reference's BSP build kept throwing")
+    cam14, res = g[stem + "/cam14"], (120, 90)
+    ref.set_camera(h, cam14, res)
+    ne = ref.rad_setup(h)
+    B = 0.05 + 4.0 * ((np.arange(ne) * 7919) % ne) / ne
+    ref.rad_set_element_radiosity(h, B)
+    px = np.zeros((res[1], res[0], 3), np.uint8)
+    assert ref.lib.ref_adapter_radiosity_raster(h, _p(px)) == 0, ref.lib.ref_adapter_error()
+    o, d, _ = frame_rays(oracle, cam14, res)
+    want = ref.tone_map_radiosity(ref.rad_trace_ray(h, o, d))
+    assert np.array_equal(px.reshape(-1, 3), want)
+    assert (want[:, 0] != want[:, 1]).any() and len(np.unique(want[:, 0])) > 20     # Green pixels and a range of greys
