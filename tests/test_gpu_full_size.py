@@ -138,3 +138,55 @@ def test_c5_solver_known_answer_64k(rt):
     assert np.linalg.norm(got - c[None, :]) / np.linalg.norm(np.tile(c, (n, 1))) < 1e-4     # the north star's bar
     assert np.max(np.abs(got / c[None, :] - 1)) < 2e-5
     assert 5 < stats.sweeps < 60
+
+
+def test_frame_path_full_size_properties(rt, oracle, monkeypatch):
+    """1920x1080 frames of the 147 K-triangle studio through rtmi_render_frame_dev (depth 3, 10 AO rays): properties that
+    do not depend on the size — (a) a sample of pixels equals the oracle's recursion (same seeded AO stream), (b) the
+    frame does not depend on how it is cut into chunks or tiles, nor on the order in which the compacted generations
+    happened to be filled (two runs are identical), (c) emission is linear: with ambient 0 the frame lit by two lights is
+    the sum of the frames lit by each alone where light 0 casts no shadow."""
+    import torch
+    from raytracer_amd import workloads as W
+    verts, obj, mats, lights = W.studio(64, 0.1)
+    nrm = W.face_normals(verts)
+    scene = rt.Scene(verts, obj)
+    cam = rt.Camera.from_cam14(W.STUDIO_CAM14, (1920, 1080))
+    sh = rt.Shader(scene, nrm, mats, lights, max_tree_depth=3, ao_rays=10, seed=4)
+    rgb, pix = sh.Rasterize(cam)
+    # (a)
+    rng = np.random.default_rng(3)
+    pl = np.stack([rng.integers(0, 1080, 3000), rng.integers(0, 1920, 3000)], 1).astype(np.uint32)
+    d = oracle.primary_dirs(oracle.raster_details(W.STUDIO_CAM14, 1920, 1080), pl)
+    o = np.tile(W.STUDIO_CAM14[:3], (len(d), 1))
+    bvh = oracle.bvh_build(verts)
+    idx = pl[:, 0].astype(np.int64) * 1920 + pl[:, 1]
+    want = np.concatenate([oracle.trace(verts, nrm, obj, mats, lights, o[i:i + 1], d[i:i + 1], max_depth=3, ao_rays=10, seed=4,
+                                        first_index=int(idx[i]), bvh=bvh) for i in range(len(pl))])
+    oracle.bvh_free(bvh)
+    assert np.abs(rgb.reshape(-1, 3)[idx] - want).max() < 1e-11
+    # (b)
+    again, _ = sh.Rasterize(cam)
+    assert np.array_equal(again, rgb)
+    monkeypatch.setenv("RTMI_SHADE_WS_MB", "256")
+    sh_small = rt.Shader(scene, nrm, mats, lights, max_tree_depth=3, ao_rays=10, seed=4)
+    chunks, _ = sh_small.Rasterize(cam)
+    monkeypatch.delenv("RTMI_SHADE_WS_MB")
+    assert np.array_equal(chunks, rgb)
+    parts = [sh.Rasterize(cam, tile=(64, 64), tile_first=r, tile_stride=4)[0] for r in range(4)]
+    assert np.array_equal(sum(parts), rgb) and all(((p != 0).any(2)).sum() > 400000 for p in parts)
+    # (c)
+    _, _, mats0, _ = W.studio(64, 0.0)
+    far = lights.copy()
+    far[0, :3] = [0.0, 0.0, 1.0e6]            # light 0 (the shadow caster) straight above, nothing above the scene's top faces
+    f01, _ = rt.Shader(scene, nrm, mats0, far, max_tree_depth=1, ao_rays=0).Rasterize(cam)
+    l0 = far.copy(); l0[1, 3:] = 0.0
+    l1 = far.copy(); l1[0, 3:] = 0.0
+    f0, _ = rt.Shader(scene, nrm, mats0, l0, max_tree_depth=1, ao_rays=0).Rasterize(cam)
+    f1, _ = rt.Shader(scene, nrm, mats0, l1, max_tree_depth=1, ao_rays=0).Rasterize(cam)
+    hits = torch.zeros(1920 * 1080 * 24, dtype=torch.uint8, device="cuda")
+    scene.primary_dev(cam, hits.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ob = hits.cpu().numpy().view(rt.HIT_DTYPE)["object"].reshape(1080, 1920)
+    lin = (ob != rt.MISS) & (ob != 3)          # object 3 = the microfacet box
+    assert lin.sum() > 1000000 and np.abs((f0 + f1) - f01)[lin].max() < 1e-12
