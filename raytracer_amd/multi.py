@@ -3,6 +3,8 @@
   * ray queries: BVH and triangles replicated; image tiles dealt round-robin (rank r traces tiles
     r, r+W, r+2W, ...) — no collective, each rank writes its own pixels of the frame.
   * form factors: rank r owns rows rows_of_rank(n, r, W) of F — no collective.
+  * whole frames: each rank renders its tiles into a zeroed full-size buffer; render_frame_sharded() assembles the image
+    on every rank with ONE all-reduce (sum: every pixel is written by exactly one rank).
   * solve: F stays row-sharded; after each Jacobi sweep the ranks all-gather their rows of B
     (RCCL over xGMI on the GPU box, gloo in the CPU tests) and all-reduce the three norms.
 
@@ -89,3 +91,31 @@ def solve_sharded(sweep, E, n, tol_rel=1e-7, max_sweeps=1000, check_every=4, gro
             if rel <= tol_rel:
                 break
     return SolveResult(B[:n], sweeps, rel, mx)
+
+
+def assemble_frame(frame, group=None):
+    """frame: a full-size tensor (bytes or doubles) holding THIS rank's tiles and zeros elsewhere.  Returns the whole
+    image on every rank: every pixel belongs to exactly one rank, so a sum over ranks is the image."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return frame
+    if frame.is_cuda and dist.get_backend(group) == "gloo":   # rehearsal only: stage through the host
+        h = frame.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        frame.copy_(h)
+    else:
+        dist.all_reduce(frame, op=dist.ReduceOp.SUM, group=group)
+    return frame
+
+
+def render_frame_sharded(render, x_res, y_res, tile=(64, 64), dtype=None, device="cuda", group=None):
+    """render(out, tile, tile_first, tile_stride) fills this rank's tiles of `out` (y_res x x_res x 3, zeroed here) —
+    Shader.render_frame_dev / rtmi_radiosity_raster_dev with tile_first = rank, tile_stride = world in production.
+    Returns the assembled frame on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    out = torch.zeros((y_res, x_res, 3), dtype=dtype or torch.uint8, device=device)
+    render(out, tile, rank, world)
+    return assemble_frame(out, group)

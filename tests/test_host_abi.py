@@ -126,6 +126,41 @@ def test_sharded_solve_world2_gloo(tmp_path, oracle):
     assert B0[ne, 0] == 68500.0
 
 
+FRAME_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from raytracer_amd import multi
+rank, world = int(sys.argv[2]), int(sys.argv[3])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+X, Y = 150, 70
+full = (np.arange(Y * X * 3).reshape(Y, X, 3) * 7 % 251).astype(np.uint8)
+def render(out, tile, first, stride):            # CPU stand-in for rtmi_render_frame_dev: writes this rank's tiles only
+    tx = (X + tile[0] - 1) // tile[0]
+    for t in multi.tiles_of_rank(X, Y, tile[0], tile[1], first, stride):
+        x0, y0 = (t % tx) * tile[0], (t // tx) * tile[1]
+        out[y0:y0 + tile[1], x0:x0 + tile[0]] = torch.from_numpy(full[y0:y0 + tile[1], x0:x0 + tile[0]])
+img = multi.render_frame_sharded(render, X, Y, tile=(32, 24), device="cpu")
+assert np.array_equal(img.numpy(), full), "assembled frame differs"
+rgb = multi.render_frame_sharded(lambda o, t, f, s: render(o, t, f, s), X, Y, tile=(32, 24), dtype=torch.float64, device="cpu")
+assert np.array_equal(rgb.numpy(), full.astype(np.float64))
+print(rank, "ok")
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_frame_world2_gloo(tmp_path):
+    """Two ranks, gloo: tiles dealt round-robin, one all-reduce assembles the frame on every rank."""
+    script = tmp_path / "frame_worker.py"
+    script.write_text(FRAME_WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+
+
 SCENE_STEMS = ["test1", "test2", "test5", "test6", "test7", "scene_room_bed_sample", "radiosity_test", "practice_room_enclosed"]
 
 
