@@ -15,6 +15,8 @@ struct rtmi_patches {
 	double *d_verts;   // n × 9: v1, v2, v3 in ORIGINAL order (util.cpp:113-115 samples from these)
 	double *d_normals; // n × 3: triNormal
 	double *d_area;    // n: vec3.h:116-118
+	uint32_t *d_noninv; // elements whose pseudo-inverse does not exist: inside for every point of their plane (util.cpp:146)
+	uint32_t n_noninv;
 	double *d_display; // n × 16 (display path): triNormal, triVert1, pseudo-inverse rows A, B (mat3x2.h:187-283), (−n)·v1, invertible, pad
 };
 
@@ -27,6 +29,8 @@ constexpr uint32_t kLightStream = 0xFFFFFFFFu;
 struct rtmi_patches_dev_view { // what the display kernels read
 	const double *verts, *normals, *display;
 	uint32_t n;
+	const uint32_t *noninv;
+	uint32_t n_noninv;
 };
 
 struct PatchesDev {
@@ -334,6 +338,112 @@ __device__ __forceinline__ void display_trace(const rtmi_patches_dev_view P, con
 	emit(k, c);
 }
 
+// The same query through the BVH of the elements (the scene the patches were created on).  trace_ray's answer is the
+// lexicographic minimum of (|P − o|, element index) over the elements whose inside test passes — unless some element is
+// met at a distance of exactly 0, which the reference's loop treats as "nothing yet" (:342): such a ray (origin on an
+// element's plane, inside it) falls back to the full loop.  An accepted point lies within rounding (1e-15) of its
+// triangle, far inside the conservatively padded boxes, so every accepted element is among the leaves the LINE of the
+// ray reaches; the boxes are tested on −tb ≤ t ≤ tb with tb the best distance so far.  Elements without a pseudo-inverse
+// are inside everywhere on their plane and are tested for every ray.
+__device__ __forceinline__ bool slab_line(uint32_t wx, uint32_t wy, uint32_t wz, const RayF &r, float tb) {
+	const float ax = fmaf((float)(wx & 0xffffu), r.ax, r.blx), bx = fmaf((float)(wx >> 16), r.ax, r.bhx);
+	const float ay = fmaf((float)(wy & 0xffffu), r.ay, r.bly), by = fmaf((float)(wy >> 16), r.ay, r.bhy);
+	const float az = fmaf((float)(wz & 0xffffu), r.az, r.blz), bz = fmaf((float)(wz >> 16), r.az, r.bhz);
+	const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), -tb));
+	const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tb));
+	return tn <= tf;
+}
+
+template <class Fetch, class Emit>
+__device__ __forceinline__ void display_trace_bvh(const SceneDev &S, const rtmi_patches_dev_view P, const double *__restrict__ vertex_rad,
+                                                  uint64_t n_items, int *stack, Fetch fetch, Emit emit) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	DispRay r;
+	if (!(k < n_items && fetch(k, r))) return;
+	const D3 O = d3(r.ox, r.oy, r.oz), D = d3(r.dx, r.dy, r.dz);
+	double dist = 0.0;
+	int hit = -1;
+	bool zero = false;
+	D3 fp = d3(0, 0, 0);
+	auto test = [&](uint32_t e) { // the body of trace_ray's loop for element e, radiosity_helper.cpp:328-356
+		const double *t = P.display + (size_t)e * kDispRec;
+		const D3 n = d3(t[0], t[1], t[2]);
+		const double denom = dot(n, D);
+		if (denom != 0.0) {
+			const double tt = -1.0 * ((dot(n, O) + t[12]) / denom);
+			const D3 Pt = (tt * D) + O;
+			double u = 0.0, v = 0.0;
+			if (t[13] != 0.0) {
+				const D3 q = Pt - d3(t[3], t[4], t[5]);
+				u = t[6] * q.x + t[7] * q.y + t[8] * q.z;
+				v = t[9] * q.x + t[10] * q.y + t[11] * q.z;
+			}
+			if (u >= 0.0 && v >= 0.0 && u + v <= 1.0) {
+				const double L = sqrt(len2(Pt - O));
+				if (L == 0.0) zero = true;
+				if (hit < 0 || L < dist || (L == dist && (int)e < hit)) { fp = Pt; hit = (int)e; dist = L; }
+			}
+		}
+	};
+	for (uint32_t q = 0; q < P.n_noninv; ++q) test(P.noninv[q]);
+	const RayF rf = make_rayf(S, O.x, O.y, O.z, D.x, D.y, D.z);
+	const double dn = sqrt(len2(D));
+	auto bound = [&]() { return hit < 0 ? 3.0e38f : f32_above((dist / dn) * (1.0 + 1e-6)); };
+	float tb = bound();
+	int sp = 0, cur = S.root_ref;
+	for (uint32_t guard = 0; cur != kSentinel && guard < kGuard; ++guard) {
+		if (cur >= 0) {
+			const QNode *np = S.nodes + cur;
+			const uint4 a = np->a, b = np->b;
+			const bool h0 = slab_line(a.x, a.y, a.z, rf, tb), h1 = slab_line(a.w, b.x, b.y, rf, tb);
+			if (h0 && h1) { stack[sp * kBlock] = (int)b.w; ++sp; cur = (int)b.z; }
+			else if (h0) cur = (int)b.z;
+			else if (h1) cur = (int)b.w;
+			else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+			else cur = kSentinel;
+		} else {
+			const uint32_t code = ~(uint32_t)cur, first = code >> 3, cnt = (code & 7u) + 1u;
+			for (uint32_t i = 0; i < cnt; ++i) {
+				const uint32_t e = S.tris[first + i].orig;
+				if (P.display[(size_t)e * kDispRec + 13] != 0.0) test(e); // the others were tested above
+			}
+			tb = bound();
+			if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+			else cur = kSentinel;
+		}
+	}
+	if (zero) { // the reference's order-dependent rule for a distance of exactly 0: redo its loop as written
+		dist = 0.0; hit = -1;
+		for (uint32_t e = 0; e < P.n; ++e) {
+			const int before = hit;
+			const double dbefore = dist;
+			const D3 fbefore = fp;
+			hit = -1;
+			test(e);
+			if (hit < 0) { hit = before; dist = dbefore; fp = fbefore; }             // e is not inside: keep the state
+			else if (!(before < 0 || dbefore == 0.0 || dbefore > dist)) { hit = before; dist = dbefore; fp = fbefore; } // :342-351
+		}
+	}
+	D3 c = d3(0.0, 1.0, 0.0); // Green
+	if (hit >= 0) {
+		const double *nv = P.normals + 3 * (size_t)hit;
+		if (dot(d3(nv[0], nv[1], nv[2]), D) > 0.0) c = d3(0.0, 0.0, 0.0);
+		else {
+			const double *p = P.verts + 9 * (size_t)hit;
+			const D3 a = d3(p[0], p[1], p[2]), b = d3(p[3], p[4], p[5]), cc = d3(p[6], p[7], p[8]);
+			auto area = [](D3 A, D3 B, D3 C) { return sqrt(len2(cross(B - A, C - A))) / 2.0; };
+			const double ar = area(a, b, cc);
+			const double w1 = area(fp, b, cc) / ar, w2 = area(fp, a, cc) / ar, w3 = area(fp, a, b) / ar;
+			double f = 0.0;
+			f += (w1 * vertex_rad[3 * (size_t)hit]);
+			f += (w2 * vertex_rad[3 * (size_t)hit + 1]);
+			f += (w3 * vertex_rad[3 * (size_t)hit + 2]);
+			c = d3(f, f, f);
+		}
+	}
+	emit(k, c);
+}
+
 // ToneMapRadiosity, rasterizer.cpp:90-109
 __device__ __forceinline__ void tone_radiosity(D3 c, uint8_t *px) {
 	if (c.x == 0.0 && c.y == 1.0 && c.z == 0.0) { px[0] = 0; px[1] = 255; px[2] = 0; return; }
@@ -341,8 +451,10 @@ __device__ __forceinline__ void tone_radiosity(D3 c, uint8_t *px) {
 	px[0] = px[1] = px[2] = g;
 }
 
-__global__ void __launch_bounds__(256) k_display_rays(rtmi_patches_dev_view P, const double *__restrict__ vertex_rad,
+template <bool BVH>
+__global__ void __launch_bounds__(256) k_display_rays(SceneDev S, rtmi_patches_dev_view P, const double *__restrict__ vertex_rad,
                                                       const rtmi_ray *__restrict__ rays, uint64_t n, double *__restrict__ rgb) {
+	extern __shared__ int disp_stack[];
 	auto fetch = [&](uint64_t k, DispRay &r) {
 		const rtmi_ray &q = rays[k];
 		if (q.reserved != 0.0) return false;
@@ -350,11 +462,13 @@ __global__ void __launch_bounds__(256) k_display_rays(rtmi_patches_dev_view P, c
 		return true;
 	};
 	auto emit = [&](uint64_t k, D3 c) { rgb[3 * k] = c.x; rgb[3 * k + 1] = c.y; rgb[3 * k + 2] = c.z; };
-	display_trace(P, vertex_rad, n, fetch, emit);
+	if (BVH) display_trace_bvh(S, P, vertex_rad, n, disp_stack + threadIdx.x, fetch, emit);
+	else display_trace(P, vertex_rad, n, fetch, emit);
 }
 
 // the pixel loop of Rasterizer::Radiosity_Raster (rasterizer.cpp:436-455): items enumerate this rank's tiles
-__global__ void __launch_bounds__(256) k_display_frame(rtmi_patches_dev_view P, const double *__restrict__ vertex_rad, rtmi_camera cam,
+template <bool BVH>
+__global__ void __launch_bounds__(256) k_display_frame(SceneDev S, rtmi_patches_dev_view P, const double *__restrict__ vertex_rad, rtmi_camera cam,
                                                        double sx, double sy, uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x,
                                                        uint32_t tile_first, uint32_t tile_stride, uint64_t n_items,
                                                        double *__restrict__ rgb, uint8_t *__restrict__ pixels) {
@@ -379,7 +493,9 @@ __global__ void __launch_bounds__(256) k_display_frame(rtmi_patches_dev_view P, 
 		if (rgb) { rgb[3 * at] = c.x; rgb[3 * at + 1] = c.y; rgb[3 * at + 2] = c.z; }
 		if (pixels) tone_radiosity(c, pixels + 3 * at);
 	};
-	display_trace(P, vertex_rad, n_items, fetch, emit);
+	extern __shared__ int disp_stack[];
+	if (BVH) display_trace_bvh(S, P, vertex_rad, n_items, disp_stack + threadIdx.x, fetch, emit);
+	else display_trace(P, vertex_rad, n_items, fetch, emit);
 }
 
 __global__ void k_tone_map_radiosity(const double *__restrict__ rgb, uint64_t n, uint8_t *__restrict__ pixels) {
@@ -440,6 +556,13 @@ static void display_record(const double *t, const double *nrm, double *rec) {
 	for (int a = 0; a < 3; ++a) { A[a] = i1x * U1[a] + i1y * U2[a]; B[a] = i2x * U1[a] + i2y * U2[a]; }
 }
 
+// the BVH pays from a few hundred elements on; RTMI_DISPLAY_QUERY=1 forces the loop over all elements, =2 the BVH
+// (tests compare them)
+static bool display_uses_bvh(const rtmi_patches *P) {
+	const unsigned force = env_uint("RTMI_DISPLAY_QUERY", 0);
+	return force == 1 ? false : force == 2 ? true : P->n >= 256;
+}
+
 static int check_patches(const rtmi_patches *p, const char *who) {
 	if (!p) return fail(std::string(who) + ": patches is NULL");
 	int dev = -1;
@@ -477,15 +600,22 @@ rtmi_patches *rtmi_patches_create(rtmi_scene *s, const double *verts, const doub
 	}
 	std::vector<double> disp((size_t)n * kDispRec);
 	for (uint32_t i = 0; i < n; ++i) display_record(verts + 9 * (size_t)i, normals + 3 * (size_t)i, disp.data() + (size_t)i * kDispRec);
+	std::vector<uint32_t> noninv;
+	for (uint32_t i = 0; i < n; ++i)
+		if (disp[(size_t)i * kDispRec + 13] == 0.0) noninv.push_back(i);
 	rtmi_patches *P = new rtmi_patches();
 	P->scene = s;
 	P->n = n;
 	P->d_verts = P->d_normals = P->d_area = P->d_display = nullptr;
+	P->d_noninv = nullptr;
+	P->n_noninv = (uint32_t)noninv.size();
 	bool ok = hipMalloc(&P->d_verts, sizeof(double) * 9 * (size_t)n) == hipSuccess &&
 	          hipMalloc(&P->d_normals, sizeof(double) * 3 * (size_t)n) == hipSuccess &&
 	          hipMalloc(&P->d_area, sizeof(double) * (size_t)n) == hipSuccess &&
 	          hipMalloc(&P->d_display, sizeof(double) * kDispRec * (size_t)n) == hipSuccess;
 	ok = ok && hipMemcpy(P->d_display, disp.data(), sizeof(double) * kDispRec * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && hipMalloc(&P->d_noninv, sizeof(uint32_t) * std::max<size_t>(1, noninv.size())) == hipSuccess;
+	if (ok && !noninv.empty()) ok = hipMemcpy(P->d_noninv, noninv.data(), sizeof(uint32_t) * noninv.size(), hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(P->d_verts, verts, sizeof(double) * 9 * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(P->d_normals, normals, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(P->d_area, area.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
@@ -503,6 +633,7 @@ void rtmi_patches_destroy(rtmi_patches *P) {
 	if (P->d_normals) (void)hipFree(P->d_normals);
 	if (P->d_area) (void)hipFree(P->d_area);
 	if (P->d_display) (void)hipFree(P->d_display);
+	if (P->d_noninv) (void)hipFree(P->d_noninv);
 	delete P;
 }
 
@@ -642,8 +773,13 @@ int rtmi_radiosity_trace_dev(rtmi_patches *P, const double *d_vertex_radiosity, 
 	if (n == 0) return 0;
 	if (!d_vertex_radiosity || !d_rays || !d_rgb) return fail(std::string(who) + ": NULL argument");
 	if (n > (uint64_t)0x7fffffff * 256) return fail(std::string(who) + ": too many rays for one launch");
-	const rtmi_patches_dev_view V = {P->d_verts, P->d_normals, P->d_display, P->n};
-	hipLaunchKernelGGL(k_display_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, V, d_vertex_radiosity, d_rays, n, d_rgb);
+	const rtmi_patches_dev_view V = {P->d_verts, P->d_normals, P->d_display, P->n, P->d_noninv, P->n_noninv};
+	if (display_uses_bvh(P))
+		hipLaunchKernelGGL(k_display_rays<true>, dim3((uint32_t)((n + 255) / 256)), dim3(256), P->scene->stack_bytes, (hipStream_t)stream, P->scene->dev, V,
+		                   d_vertex_radiosity, d_rays, n, d_rgb);
+	else
+		hipLaunchKernelGGL(k_display_rays<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P->scene->dev, V, d_vertex_radiosity,
+		                   d_rays, n, d_rgb);
 	return launch_check(who);
 }
 
@@ -662,9 +798,13 @@ int rtmi_radiosity_raster_dev(rtmi_patches *P, const double *d_vertex_radiosity,
 	if (tile_first >= n_tiles) return 0;
 	const uint64_t n = ((n_tiles - tile_first + tile_stride - 1) / tile_stride) * tile_w * tile_h;
 	if (n > (uint64_t)0x7fffffff * 256) return fail(std::string(who) + ": frame too large for one launch");
-	const rtmi_patches_dev_view V = {P->d_verts, P->d_normals, P->d_display, P->n};
-	hipLaunchKernelGGL(k_display_frame, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, V, d_vertex_radiosity, *cam, sx, sy,
-	                   tile_w, tile_h, tiles_x, tile_first, tile_stride, n, d_rgb, d_pixels);
+	const rtmi_patches_dev_view V = {P->d_verts, P->d_normals, P->d_display, P->n, P->d_noninv, P->n_noninv};
+	if (display_uses_bvh(P))
+		hipLaunchKernelGGL(k_display_frame<true>, dim3((uint32_t)((n + 255) / 256)), dim3(256), P->scene->stack_bytes, (hipStream_t)stream, P->scene->dev, V,
+		                   d_vertex_radiosity, *cam, sx, sy, tile_w, tile_h, tiles_x, tile_first, tile_stride, n, d_rgb, d_pixels);
+	else
+		hipLaunchKernelGGL(k_display_frame<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P->scene->dev, V, d_vertex_radiosity,
+		                   *cam, sx, sy, tile_w, tile_h, tiles_x, tile_first, tile_stride, n, d_rgb, d_pixels);
 	return launch_check(who);
 }
 

@@ -338,3 +338,35 @@ def test_radiosity_display_path(rt, oracle, stem):
     assert np.array_equal(np.where(a != 0, a, b), rgb)
     flat, _ = rad.Radiosity_Raster(cam)
     assert np.array_equal(flat.reshape(-1, 3), oracle.radiosity_trace(G("verts"), G("normals"), np.repeat(G("B")[:, None], 3, 1), o, d))
+
+
+def test_radiosity_display_bvh_equals_the_full_loop(rt, oracle, monkeypatch):
+    """The display query through the elements' BVH gives the very colours of the reference's loop over all elements:
+    forced on for the golden scenes (10 / 48 elements) against the reference's vectors, and on the 3 888-patch box from
+    inside, from outside, and from an eye lying exactly on a wall (the distance-0 rule of trace_ray)."""
+    from raytracer_amd import workloads
+    g = load_golden("g8_radiosity_display.npz")
+    monkeypatch.setenv("RTMI_DISPLAY_QUERY", "2")
+    for stem in ("radiosity_test", "practice_room_enclosed"):
+        G = lambda k: g[stem + "/" + k]
+        rad = rt.Radiosity(rt.Scene(G("verts")), G("normals"))
+        rgb, pix = rad.Radiosity_Raster(rt.Camera.from_cam14(G("cam14"), G("res")), G("vertex_rad"))
+        k = G("pix")[:, 0].astype(np.int64), G("pix")[:, 1].astype(np.int64)
+        assert np.array_equal(rgb[k], G("rgb")) and np.array_equal(pix[k], G("pixels"))
+    verts, normals, _ = workloads.closed_box(18)
+    rad = rt.Radiosity(rt.Scene(verts), normals)
+    vr = np.random.default_rng(5).random((len(verts), 3))
+    # trace_ray takes the nearest element on the LINE of the ray, also behind the eye (and then answers Black for its back
+    # face): the eyes look toward the walls they are nearer to
+    cams = [np.array([3.0, 4.0, 6.0, 0.0, 2.0, 3.0, 0, 0, 1, 1.0, -1.0, 1.0, -0.75, 0.75]),
+            np.array([-6.0, -9.0, 14.0, 5.0, 5.0, 5.0, 0, 0, 1, 2.0, -1.0, 1.0, -0.75, 0.75]),
+            np.array([0.0, 2.5, 2.5, 9.0, 7.0, 2.0, 0, 0, 1, 1.0, -1.0, 1.0, -0.75, 0.75])]      # eye on the wall x = 0
+    for c in cams:
+        cam = rt.Camera.from_cam14(c, (320, 240))
+        monkeypatch.setenv("RTMI_DISPLAY_QUERY", "2")
+        a, _ = rad.Radiosity_Raster(cam, vr)
+        monkeypatch.setenv("RTMI_DISPLAY_QUERY", "1")
+        b, _ = rad.Radiosity_Raster(cam, vr)
+        assert np.array_equal(a, b)
+    inside, _ = rad.Radiosity_Raster(rt.Camera.from_cam14(cams[0], (320, 240)), vr)
+    assert len(np.unique(inside[..., 0])) > 1000
