@@ -25,6 +25,20 @@ struct __attribute__((aligned(16))) QNode {
 	uint4 a, b;
 };
 
+// 4-wide inner node, 48 B = THREE 16-byte loads per lane for up to four children (the binary node costs two loads per
+// two children and twice the dependent steps; tools/est_bvh4.cpp: 149 instead of 182 requests per C3 ray).  The children's
+// boxes are 8-bit coordinates on a grid local to the node: plane = origin + q·2^e per axis, origin = the node's own lo
+// corner in fp32, e the smallest exponent with 255·2^e >= the node's extent; lo planes rounded down, hi planes up.
+// Inner children come first and sit next to each other in the node array, leaf children (ONE triangle each) follow and
+// their triangles sit next to each other in the triangle array, so two bases replace four references:
+//   a = (origin.x, origin.y, origin.z [float bits], ex | ey<<8 | ez<<16 | n_inner<<24 | n_children<<28)   (e* = signed byte)
+//   b = (lo.x of children 0..3 [one byte each], hi.x, lo.y, hi.y)
+//   c = (lo.z, hi.z, index of inner child 0, ~(first << 3) with first = tri_base − n_inner: child k's leaf reference is c.w − 8k)
+// Used by the ray queries; the display pass keeps the binary nodes (its line query has its own slab test).
+struct __attribute__((aligned(16))) WNode {
+	uint4 a, b, c;
+};
+
 // Triangle in leaf order, 80 B: v0 and the two edges the reference recomputes for every test
 // (e1 = v1 − v0, e2 = v2 − v0: the same IEEE subtraction done once on the host), original id, object.
 struct __attribute__((aligned(16))) GTri {
@@ -32,7 +46,7 @@ struct __attribute__((aligned(16))) GTri {
 	uint32_t orig, object;
 };
 
-constexpr int kStackDepth = 32;   // LDS traversal stack entries per lane (builder caps the depth)
+constexpr int kStackDepth = 32;   // cap on the depth of the binary hierarchy (builder); the LDS stack of a launch is sized per scene
 constexpr int kBlock = 256;       // threads per workgroup in every traversal kernel
 constexpr int kSentinel = INT32_MIN;      // lane state: no node left (ray finished, or lane idle)
 constexpr uint32_t kGuard = 1u << 26;      // wave-iterations after which trace_queue gives up (safety net)
@@ -51,7 +65,8 @@ constexpr int kLeaf = INT32_MIN + 1;      // lane state: working through the tri
 constexpr uint32_t kMaxFirst = 1u << 27; // leaf refs ~((first << 3) | cnt-1) stay above kLeaf
 
 struct SceneDev {
-	const QNode *nodes;
+	const QNode *nodes;   // binary, display pass
+	const WNode *wnodes;  // 4-wide, ray queries; root = 0 in both when root_ref >= 0
 	float qlo[3], qstep[3]; // the quantisation grid: plane = qlo + q·qstep (q = 0..65535)
 	const GTri *tris;
 	int32_t root_ref; // kSentinel for an empty scene
@@ -128,28 +143,78 @@ __device__ __forceinline__ bool slab(uint32_t wx, uint32_t wy, uint32_t wz, cons
 	return tn <= tf;
 }
 
-// One node step of a lane: fetch the node (2 × 16 B), test both children, go to the nearer hit child and push the
-// other one, or pop.  Returns the lane's next reference (inner node, raw leaf reference, or kSentinel).
-__device__ __forceinline__ int node_step(const SceneDev &S, const RayF &r, float tbest, int cur, int &sp, int *stack) {
-	const QNode *np = S.nodes + cur;
-	const uint4 a = np->a, b = np->b;
-	float t0, t1;
-	const bool h0 = slab(a.x, a.y, a.z, r, tbest, t0);
-	const bool h1 = slab(a.w, b.x, b.y, r, tbest, t1);
-	const int r0 = (int)b.z, r1 = (int)b.w;
-	if (h0 && h1) {
-		const bool swap = t1 < t0;
-		stack[sp * kBlock] = swap ? r0 : r1;
-		++sp;
-		return swap ? r1 : r0;
+// ---------------------------------------------------------------- the 4-wide node step of the ray queries
+// t(plane) = (origin + q·2^e − (o ± pad))/d = q·(2^e/d) + (origin/d − (o ± pad)/d): 2^e/d is exact (v_ldexp_f32), the
+// addend costs one fused multiply-add per axis and side and node on the pre-rounded −(o ± pad)/d, then ONE fused
+// multiply-add per plane on the byte (v_cvt_f32_ubyteN).  Which plane of an axis the ray enters through is known from
+// the sign of d, so the node's lo/hi words are swapped once per node and no per-child min/max pair is needed.
+// Rounding errors: a few 2^-24·|coord| in distance units, far below the pad (as above).
+struct RayW {
+	float ix, iy, iz;    // 1/d, |d| clamped away from 0
+	float cnx, cny, cnz; // addend of the entry planes: −(o + pad)/d for d >= 0 (lo plane), −(o − pad)/d for d < 0 (hi plane)
+	float cfx, cfy, cfz; // addend of the exit planes: the other one
+};
+
+__device__ __forceinline__ RayW make_rayw(const SceneDev &S, double ox, double oy, double oz, double dx, double dy, double dz) {
+	const float fx = (float)ox, fy = (float)oy, fz = (float)oz;
+	const float pad = 3.814697265625e-06f * (S.absmax + fmaxf(fabsf(fx), fmaxf(fabsf(fy), fabsf(fz)))) + 1e-30f;
+	RayW r;
+	r.ix = safe_rcp((float)dx); r.iy = safe_rcp((float)dy); r.iz = safe_rcp((float)dz);
+	const float lx = -(fx + pad) * r.ix, ly = -(fy + pad) * r.iy, lz = -(fz + pad) * r.iz;
+	const float hx = -(fx - pad) * r.ix, hy = -(fy - pad) * r.iy, hz = -(fz - pad) * r.iz;
+	r.cnx = r.ix < 0.f ? hx : lx; r.cny = r.iy < 0.f ? hy : ly; r.cnz = r.iz < 0.f ? hz : lz;
+	r.cfx = r.ix < 0.f ? lx : hx; r.cfy = r.iy < 0.f ? ly : hy; r.cfz = r.iz < 0.f ? lz : hz;
+	return r;
+}
+
+template <int K> __device__ __forceinline__ float ubyte(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }
+__device__ __forceinline__ int sbyte(uint32_t w, int k) { return (int)(w << (24 - 8 * k)) >> 24; }
+
+// One node step of a lane: fetch the node (3 × 16 B), test its children, go to the nearest hit child and push the others
+// (farthest first), or pop.  Returns the lane's next reference (inner node, raw leaf reference, or kSentinel).
+// A hit child is carried as ONE sortable word: the bits of its entry distance (>= 0, so they order like the float) with
+// the child's number in the two lowest bits; 0xffffffff = not hit.  Five min/max pairs sort the four words.
+__device__ __forceinline__ int node_step(const SceneDev &S, const RayW &r, float tbest, int cur, int &sp, int *stack) {
+	const WNode *np = S.wnodes + cur;
+	const uint4 a = np->a, b = np->b, c = np->c;
+	const float ax = ldexpf(r.ix, sbyte(a.w, 0)), ay = ldexpf(r.iy, sbyte(a.w, 1)), az = ldexpf(r.iz, sbyte(a.w, 2));
+	const float px = __uint_as_float(a.x), py = __uint_as_float(a.y), pz = __uint_as_float(a.z);
+	const float bnx = fmaf(px, r.ix, r.cnx), bny = fmaf(py, r.iy, r.cny), bnz = fmaf(pz, r.iz, r.cnz);
+	const float bfx = fmaf(px, r.ix, r.cfx), bfy = fmaf(py, r.iy, r.cfy), bfz = fmaf(pz, r.iz, r.cfz);
+	const bool sx = r.ix < 0.f, sy = r.iy < 0.f, sz = r.iz < 0.f;
+	const uint32_t nxw = sx ? b.y : b.x, fxw = sx ? b.x : b.y;
+	const uint32_t nyw = sy ? b.w : b.z, fyw = sy ? b.z : b.w;
+	const uint32_t nzw = sz ? c.y : c.x, fzw = sz ? c.x : c.y;
+	const uint32_t n_inner = (a.w >> 24) & 0xfu, n_child = a.w >> 28;
+	uint32_t key[4];
+#define RTMI_CHILD(K)                                                                                                         \
+	{                                                                                                                         \
+		const float tn = fmaxf(fmaxf(fmaf(ubyte<K>(nxw), ax, bnx), fmaf(ubyte<K>(nyw), ay, bny)), fmaxf(fmaf(ubyte<K>(nzw), az, bnz), 0.0f)); \
+		const float tf = fminf(fminf(fmaf(ubyte<K>(fxw), ax, bfx), fmaf(ubyte<K>(fyw), ay, bfy)), fminf(fmaf(ubyte<K>(fzw), az, bfz), tbest)); \
+		key[K] = (tn <= tf && n_child > K) ? ((__float_as_uint(tn) & ~3u) | K) : 0xffffffffu;                                  \
 	}
-	if (h0) return r0;
-	if (h1) return r1;
-	if (sp > 0) {
-		--sp;
-		return stack[sp * kBlock];
+	RTMI_CHILD(0) RTMI_CHILD(1) RTMI_CHILD(2) RTMI_CHILD(3)
+#undef RTMI_CHILD
+#define RTMI_CE(I, J)                                                                                                         \
+	{                                                                                                                         \
+		const uint32_t lo = min(key[I], key[J]), hi = max(key[I], key[J]);                                                    \
+		key[I] = lo; key[J] = hi;                                                                                             \
 	}
-	return kSentinel;
+	RTMI_CE(0, 1) RTMI_CE(2, 3) RTMI_CE(0, 2) RTMI_CE(1, 3) RTMI_CE(1, 2)
+#undef RTMI_CE
+	// child k: inner -> c.z + k;  leaf -> ~((first + k) << 3) = c.w − 8k with c.w = ~(first << 3) (one triangle: count − 1 = 0)
+	auto ref_of = [&](uint32_t k) -> int { return k < n_inner ? (int)(c.z + k) : (int)(c.w - (k << 3)); };
+	if (key[0] == 0xffffffffu) {
+		if (sp > 0) {
+			--sp;
+			return stack[sp * kBlock];
+		}
+		return kSentinel;
+	}
+	if (key[3] != 0xffffffffu) { stack[sp * kBlock] = ref_of(key[3] & 3u); ++sp; }
+	if (key[2] != 0xffffffffu) { stack[sp * kBlock] = ref_of(key[2] & 3u); ++sp; }
+	if (key[1] != 0xffffffffu) { stack[sp * kBlock] = ref_of(key[1] & 3u); ++sp; }
+	return ref_of(key[0] & 3u);
 }
 
 // float >= x (x >= 0)
@@ -177,7 +242,7 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 	h.pos = RTMI_MISS;
 	double best = tmax;
 	float tbest = f32_above(best);
-	const RayF r = make_rayf(S, ox, oy, oz, dx, dy, dz);
+	const RayW r = make_rayw(S, ox, oy, oz, dx, dy, dz);
 	int sp = 0;
 	int cur = S.root_ref;
 	uint32_t tk = 0, tend = 0;
@@ -254,7 +319,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
                                             Emit emit, Work *w = nullptr) {
 	const uint32_t lane = threadIdx.x & 63u;
 	RayD R = {0, 0, 0, 0, 0, 1, 0};
-	RayF r = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	RayW r = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	HitQ h = {0.0, 0.f, 0.f, RTMI_MISS};
 	double best = 0.0;
 	float tbest = 0.f;
@@ -269,7 +334,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 		h.u = h.v = 0.f; h.pos = RTMI_MISS;
 		best = R.tmax;
 		tbest = f32_above(best);
-		r = make_rayf(S, UNIFORM_O ? uox : R.ox, UNIFORM_O ? uoy : R.oy, UNIFORM_O ? uoz : R.oz, R.dx, R.dy, R.dz);
+		r = make_rayw(S, UNIFORM_O ? uox : R.ox, UNIFORM_O ? uoy : R.oy, UNIFORM_O ? uoz : R.oz, R.dx, R.dy, R.dz);
 		sp = 0;
 		cur = S.root_ref;
 	};

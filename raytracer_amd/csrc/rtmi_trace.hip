@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -195,7 +196,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	for (uint64_t i = 0; i < 9 * n; ++i)
 		if (!std::isfinite(xyz[i])) { fail("rtmi_scene_create: non-finite vertex coordinate"); return nullptr; }
 	auto t0 = std::chrono::steady_clock::now();
-	const unsigned leaf = std::min(8u, env_uint("RTMI_LEAF", 1));
+	const unsigned leaf = 1; // the 4-wide nodes address a leaf child as ONE triangle (rtmi_device.hpp, WNode)
 	const unsigned threads = std::min(env_uint("RTMI_BUILD_THREADS", std::max(1u, std::thread::hardware_concurrency())), 16u);
 	Bvh2 bvh = build_bvh2(xyz, n, leaf, kStackDepth - 2, threads);
 	if (n > 0 && bvh.depth > (uint32_t)kStackDepth - 1) { fail("rtmi_scene_create: BVH deeper than the traversal stack"); return nullptr; }
@@ -211,7 +212,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	std::memcpy(s->info.scene_lo, bvh.lo, sizeof bvh.lo);
 	std::memcpy(s->info.scene_hi, bvh.hi, sizeof bvh.hi);
 	if (hipGetDevice(&s->device) != hipSuccess) { delete s; fail("hipGetDevice failed"); return nullptr; }
-	s->dev.nodes = nullptr; s->dev.tris = nullptr; s->dev.root_ref = kSentinel; s->dev.absmax = 0.f;
+	s->dev.nodes = nullptr; s->dev.wnodes = nullptr; s->dev.tris = nullptr; s->dev.root_ref = kSentinel; s->dev.absmax = 0.f;
 	for (int a = 0; a < 3; ++a) { s->dev.qlo[a] = 0.f; s->dev.qstep[a] = 0.f; }
 	s->d_v1_orig = nullptr;
 	s->d_queue = nullptr;
@@ -221,16 +222,120 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		s->n_cus = (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
 	}
 	if (hipMalloc(&s->d_queue, kQueueSlots * sizeof(int)) != hipSuccess) { delete s; fail("rtmi_scene_create: hipMalloc failed"); return nullptr; }
-	// one push per inner node on a root-to-leaf path at most: depth entries, +1 spare
+	// binary hierarchy (display pass): one push per inner node on a root-to-leaf path at most; the 4-wide one may need more
 	s->stack_bytes = (bvh.depth + 1u) * kBlock * (uint32_t)sizeof(int);
 	if (n == 0) return s;
 
-	// leaf-ordered triangles
+	// ---- the 4-wide hierarchy of the ray queries: collapse, lay out, quantise (WNode, rtmi_device.hpp) -------------
+	// A node adopts grandchildren, always opening the inner child with the largest surface area, until it has four
+	// children or only leaves.  Inner children first (consecutive node slots), then the leaves (consecutive triangle
+	// positions); nodes in depth-first order.  leaf_pos[build node] = position of a leaf's triangle.
+	std::vector<uint32_t> leaf_pos(bvh.nodes.size(), 0u);
+	std::vector<WNode> wnodes;
+	uint32_t wide_need = 0; // stack entries the deepest path of the 4-wide hierarchy can hold
+	{
+		auto area = [&](int32_t i) {
+			const BuildNode &x = bvh.nodes[i];
+			const float d0 = x.hi[0] - x.lo[0], d1 = x.hi[1] - x.lo[1], d2 = x.hi[2] - x.lo[2];
+			return d0 * d1 + d1 * d2 + d0 * d2;
+		};
+		uint32_t next_tri = 0;
+		if (bvh.nodes[0].left < 0) {
+			if (bvh.nodes[0].count != 1) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: a leaf with more than one triangle"); return nullptr; }
+			leaf_pos[0] = next_tri++;
+		} else {
+			struct Item { uint32_t build_id, out_id; };
+			std::vector<Item> todo;
+			std::vector<uint32_t> kids_of; // per wide node: n_children | first inner child << 4 (for the stack bound below)
+			wnodes.reserve(bvh.nodes.size() / 3 + 1);
+			wnodes.emplace_back();
+			todo.push_back({0u, 0u});
+			while (!todo.empty()) {
+				const Item it = todo.back();
+				todo.pop_back();
+				const BuildNode &x = bvh.nodes[it.build_id];
+				int32_t kid[4] = {x.left, x.right, -1, -1};
+				int nk = 2;
+				while (nk < 4) {
+					int best = -1;
+					float ba = -1.f;
+					for (int k = 0; k < nk; ++k)
+						if (bvh.nodes[kid[k]].left >= 0 && area(kid[k]) > ba) { ba = area(kid[k]); best = k; }
+					if (best < 0) break;
+					const BuildNode &c = bvh.nodes[kid[best]];
+					kid[best] = c.left;
+					kid[nk++] = c.right;
+				}
+				std::stable_partition(kid, kid + nk, [&](int32_t k) { return bvh.nodes[k].left >= 0; });
+				int ni = 0;
+				while (ni < nk && bvh.nodes[kid[ni]].left >= 0) ++ni;
+				const uint32_t inner_base = (uint32_t)wnodes.size(), tri_base = next_tri;
+				for (int k = 0; k < ni; ++k) wnodes.emplace_back();
+				for (int k = ni - 1; k >= 0; --k) todo.push_back({(uint32_t)kid[k], inner_base + (uint32_t)k}); // child 0 is laid out next
+				for (int k = ni; k < nk; ++k) {
+					if (bvh.nodes[kid[k]].count != 1) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: a leaf with more than one triangle"); return nullptr; }
+					leaf_pos[kid[k]] = next_tri++;
+				}
+				// the node's grid: origin = its lo corner, step 2^e with 255·2^e >= extent (e as a signed byte)
+				uint32_t eb[3];
+				double st[3];
+				for (int a = 0; a < 3; ++a) {
+					const double ext = (double)x.hi[a] - (double)x.lo[a];
+					int e = -126;
+					while (e < 127 && std::ldexp(255.0, e) < ext) ++e;
+					eb[a] = (uint32_t)(e & 0xff);
+					st[a] = std::ldexp(1.0, e);
+				}
+				uint32_t w[6] = {0, 0, 0, 0, 0, 0}; // lo.x, hi.x, lo.y, hi.y, lo.z, hi.z: one byte per child
+				for (int k = 0; k < nk; ++k) {
+					const BuildNode &c = bvh.nodes[kid[k]];
+					for (int a = 0; a < 3; ++a) {
+						// origin + q·2^e is exact in double (q <= 255): the quantised box contains the fp32 box
+						double ql = std::floor(((double)c.lo[a] - (double)x.lo[a]) / st[a]);
+						double qh = std::ceil(((double)c.hi[a] - (double)x.lo[a]) / st[a]);
+						ql = std::min(255.0, std::max(0.0, ql));
+						qh = std::min(255.0, std::max(0.0, qh));
+						while (ql > 0.0 && (double)x.lo[a] + ql * st[a] > (double)c.lo[a]) ql -= 1.0;
+						while (qh < 255.0 && (double)x.lo[a] + qh * st[a] < (double)c.hi[a]) qh += 1.0;
+						w[2 * a] |= (uint32_t)ql << (8 * k);
+						w[2 * a + 1] |= (uint32_t)qh << (8 * k);
+					}
+				}
+				auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+				WNode g;
+				g.a = make_uint4(fbits(x.lo[0]), fbits(x.lo[1]), fbits(x.lo[2]), eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)ni << 24) | ((uint32_t)nk << 28));
+				g.b = make_uint4(w[0], w[1], w[2], w[3]);
+				g.c = make_uint4(w[4], w[5], inner_base, ~((tri_base - (uint32_t)ni) << 3));
+				wnodes[it.out_id] = g;
+				if (kids_of.size() < wnodes.size()) kids_of.resize(wnodes.size(), 0u);
+				kids_of[it.out_id] = (uint32_t)nk | ((uint32_t)ni << 4);
+			}
+			// stack bound: on the way down a node leaves at most n_children − 1 entries behind; children have larger indices
+			std::vector<uint32_t> need(wnodes.size(), 0u);
+			for (size_t i = wnodes.size(); i-- > 0;) {
+				const uint32_t nk = kids_of[i] & 15u, ni = kids_of[i] >> 4, base = wnodes[i].c.z;
+				uint32_t below = 0;
+				for (uint32_t k = 0; k < ni; ++k) below = std::max(below, need[base + k]);
+				need[i] = nk - 1u + below;
+			}
+			wide_need = need[0];
+		}
+		if (next_tri != n) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: internal error: the 4-wide layout lost triangles"); return nullptr; }
+	}
+	if ((wide_need + 1u) * kBlock * sizeof(int) > 64u * 1024u) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: BVH deeper than the traversal stack"); return nullptr; }
+	s->stack_bytes = (std::max(bvh.depth, wide_need) + 1u) * kBlock * (uint32_t)sizeof(int);
+	if (env_uint("RTMI_VERBOSE", 0))
+		std::fprintf(stderr, "rtmi_scene_create: %zu binary nodes of depth %u, %zu 4-wide nodes needing %u stack entries, %u B of LDS per workgroup\n",
+		             bvh.nodes.size(), bvh.depth, wnodes.size(), wide_need, s->stack_bytes);
+
+	// leaf-ordered triangles (position = leaf_pos of their leaf)
 	std::vector<GTri> tris(n);
-	for (uint64_t k = 0; k < n; ++k) {
-		const uint32_t id = bvh.order[k];
+	for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+		const BuildNode &bn = bvh.nodes[i];
+		if (bn.left >= 0) continue;
+		const uint32_t id = bvh.order[bn.first];
 		const double *p = xyz + 9 * (uint64_t)id;
-		GTri &T = tris[k];
+		GTri &T = tris[leaf_pos[i]];
 		for (int a = 0; a < 3; ++a) {
 			T.v0[a] = p[a];
 			T.e1[a] = p[3 + a] - p[a]; // Render2/object.cpp:36
@@ -239,8 +344,8 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		T.orig = id;
 		T.object = obj ? obj[id] : 0u;
 	}
-	// inner nodes in depth-first order (a node's near subtree follows it in memory)
-	auto ref_of_leaf = [](const BuildNode &b) { return (int32_t) ~((b.first << 3) | (b.count - 1)); };
+	// ---- the binary nodes of the display pass: depth-first order (a node's near subtree follows it in memory)
+	auto ref_of_leaf = [&](int32_t build_id) { return (int32_t) ~(leaf_pos[build_id] << 3); };
 	// the 16-bit grid over the scene bounds: plane = qlo + q·qstep, evaluated by the kernels in fp32.  qstep is
 	// rounded up until qlo + 65535·qstep covers the scene; lo planes are rounded down and hi planes up against
 	// the very values the kernels use, so a quantised box always contains the fp32 box.
@@ -271,7 +376,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	const BuildNode &root = bvh.nodes[0];
 	int32_t root_ref;
 	if (root.left < 0) {
-		root_ref = ref_of_leaf(root);
+		root_ref = ref_of_leaf(0);
 	} else {
 		nodes.reserve(bvh.nodes.size() / 2 + 1);
 		struct Item { uint32_t build_id; int32_t out_id; };
@@ -285,9 +390,9 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 			const BuildNode &c0 = bvh.nodes[b.left], &c1 = bvh.nodes[b.right];
 			int32_t r0, r1;
 			// allocate right first so that the left child is processed (and laid out) first
-			if (c1.left < 0) r1 = ref_of_leaf(c1);
+			if (c1.left < 0) r1 = ref_of_leaf(b.right);
 			else { r1 = (int32_t)nodes.size(); nodes.emplace_back(); todo.push_back({(uint32_t)b.right, r1}); }
-			if (c0.left < 0) r0 = ref_of_leaf(c0);
+			if (c0.left < 0) r0 = ref_of_leaf(b.left);
 			else { r0 = (int32_t)nodes.size(); nodes.emplace_back(); todo.push_back({(uint32_t)b.left, r0}); }
 			QNode g;
 			g.a = make_uint4(plane_word(c0, 0), plane_word(c0, 1), plane_word(c0, 2), plane_word(c1, 0));
@@ -303,11 +408,13 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	for (uint64_t k = 0; k < n; ++k)
 		for (int a = 0; a < 3; ++a) v1[3 * k + a] = xyz[9 * k + a];
 	QNode *d_nodes = nullptr;
+	WNode *d_wnodes = nullptr;
 	GTri *d_tris = nullptr;
-	const size_t nb = std::max<size_t>(1, nodes.size()) * sizeof(QNode), tb = tris.size() * sizeof(GTri);
-	if (hipMalloc(&d_nodes, nb) != hipSuccess || hipMalloc(&d_tris, tb) != hipSuccess ||
+	const size_t nb = std::max<size_t>(1, nodes.size()) * sizeof(QNode), wb = std::max<size_t>(1, wnodes.size()) * sizeof(WNode), tb = tris.size() * sizeof(GTri);
+	if (hipMalloc(&d_nodes, nb) != hipSuccess || hipMalloc(&d_wnodes, wb) != hipSuccess || hipMalloc(&d_tris, tb) != hipSuccess ||
 	    hipMalloc(&s->d_v1_orig, v1.size() * sizeof(double)) != hipSuccess) {
 		if (d_nodes) (void)hipFree(d_nodes);
+		if (d_wnodes) (void)hipFree(d_wnodes);
 		if (d_tris) (void)hipFree(d_tris);
 		if (s->d_v1_orig) (void)hipFree(s->d_v1_orig);
 		(void)hipFree(s->d_queue);
@@ -317,18 +424,19 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	}
 	bool ok = true;
 	if (!nodes.empty()) ok = ok && hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(QNode), hipMemcpyHostToDevice) == hipSuccess;
+	if (!wnodes.empty()) ok = ok && hipMemcpy(d_wnodes, wnodes.data(), wnodes.size() * sizeof(WNode), hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(d_tris, tris.data(), tb, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(s->d_v1_orig, v1.data(), v1.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
 	if (!ok) {
-		(void)hipFree(d_nodes); (void)hipFree(d_tris); (void)hipFree(s->d_v1_orig); (void)hipFree(s->d_queue);
+		(void)hipFree(d_nodes); (void)hipFree(d_wnodes); (void)hipFree(d_tris); (void)hipFree(s->d_v1_orig); (void)hipFree(s->d_queue);
 		delete s;
 		fail("rtmi_scene_create: upload failed");
 		return nullptr;
 	}
-	s->dev.nodes = d_nodes; s->dev.tris = d_tris; s->dev.root_ref = root_ref; s->dev.absmax = absmax;
+	s->dev.nodes = d_nodes; s->dev.wnodes = d_wnodes; s->dev.tris = d_tris; s->dev.root_ref = root_ref; s->dev.absmax = absmax;
 	for (int a = 0; a < 3; ++a) { s->dev.qlo[a] = qlo[a]; s->dev.qstep[a] = qstep[a]; }
 	s->info.n_nodes = nodes.size();
-	s->info.device_bytes = nb + tb + v1.size() * sizeof(double);
+	s->info.device_bytes = nb + wb + tb + v1.size() * sizeof(double);
 	s->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	return s;
 }
@@ -436,6 +544,7 @@ rtmi_scene *rtmi_scene_create(const double *tri_xyz, const uint32_t *tri_object,
 void rtmi_scene_destroy(rtmi_scene *s) {
 	if (!s) return;
 	if (s->dev.nodes) (void)hipFree((void *)s->dev.nodes);
+	if (s->dev.wnodes) (void)hipFree((void *)s->dev.wnodes);
 	if (s->dev.tris) (void)hipFree((void *)s->dev.tris);
 	if (s->d_v1_orig) (void)hipFree(s->d_v1_orig);
 	if (s->d_queue) (void)hipFree(s->d_queue);

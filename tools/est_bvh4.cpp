@@ -38,12 +38,14 @@ static double mt(const double *p, const Ray &r) {
 	return (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
 }
 
-struct Wide { int n; int child[8]; }; // child: index into bvh.nodes (inner or leaf)
+struct Wide { int n; int child[8]; float lo[8][3], hi[8][3]; }; // child: index into bvh.nodes (inner or leaf); boxes as the node stores them
+static int g_bits = 0; // 0: the children's fp32 boxes; else planes of g_bits bits relative to the node's box, step a power of two
 
 int main(int argc, char **argv) {
 	const uint64_t n = argc > 1 ? strtoull(argv[1], 0, 10) : (1u << 20);
 	const int width = argc > 2 ? atoi(argv[2]) : 4;
 	const double edge = argc > 3 ? atof(argv[3]) : 0.01;
+	g_bits = argc > 4 ? atoi(argv[4]) : 0;
 	std::mt19937_64 g(1);
 	std::uniform_real_distribution<double> U(-1, 1), E(-edge, edge);
 	std::vector<double> xyz(9 * n);
@@ -70,6 +72,17 @@ int main(int argc, char **argv) {
 			const BuildNode &c = b.nodes[w.child[best]];
 			w.child[best] = c.left; w.child[w.n++] = c.right;
 		}
+		for (int k = 0; k < w.n; ++k)
+			for (int a = 0; a < 3; ++a) {
+				const BuildNode &c = b.nodes[w.child[k]];
+				if (!g_bits) { w.lo[k][a] = c.lo[a]; w.hi[k][a] = c.hi[a]; continue; }
+				const double qmax = (double)((1 << g_bits) - 1), ext = (double)x.hi[a] - x.lo[a];
+				int e = -126;
+				while (std::ldexp(qmax, e) < ext) ++e;
+				const double st = std::ldexp(1.0, e);
+				w.lo[k][a] = (float)(x.lo[a] + std::floor(((double)c.lo[a] - x.lo[a]) / st) * st);
+				w.hi[k][a] = (float)(x.lo[a] + std::min(qmax, std::ceil(((double)c.hi[a] - x.lo[a]) / st)) * st);
+			}
 		wide[i] = w; ++n_wide; n_children += w.n;
 		for (int k = 0; k < w.n; ++k) todo.push_back(w.child[k]);
 	}
@@ -101,11 +114,13 @@ int main(int argc, char **argv) {
 						(mode ? v4 : v2)++;
 						Ent e[8]; int m = 0;
 						Wide w2; w2.n = 2; w2.child[0] = x.left; w2.child[1] = x.right;
+						for (int k = 0; k < 2 && !mode; ++k)
+							for (int a = 0; a < 3; ++a) { w2.lo[k][a] = b.nodes[w2.child[k]].lo[a]; w2.hi[k][a] = b.nodes[w2.child[k]].hi[a]; }
 						const Wide &w = mode ? wide[cur] : w2;
 						if (mode) boxes4 += w.n;
 						for (int k = 0; k < w.n; ++k) {
 							float tn;
-							if (slab(b.nodes[w.child[k]].lo, b.nodes[w.child[k]].hi, r, tbest, tn)) e[m++] = {w.child[k], tn};
+							if (slab(w.lo[k], w.hi[k], r, tbest, tn)) e[m++] = {w.child[k], tn};
 						}
 						std::sort(e, e + m, [](const Ent &a, const Ent &c) { return a.t > c.t; }); // far first
 						for (int k = 0; k < m; ++k) stack[sp++] = e[k];
@@ -120,7 +135,9 @@ int main(int argc, char **argv) {
 	printf("rays %llu, hits %llu / %llu\n", rays, hits2, hits4);
 	printf("binary : %.1f visits, %.2f triangle tests per ray -> %.0f requests (2 per visit, 5 per test), %.0f B of nodes\n", v2 / R, t2 / R,
 	       (2.0 * v2 + 5.0 * t2) / R, 32.0 * v2 / R);
-	const int per = (width * 16 + 15) / 16; // 16-bit planes: 12 B + 4 B ref per child
+	// 16-bit planes on the scene grid: 12 B + 4 B reference per child; b-bit planes relative to the node: 12 B origin,
+	// 4 B exponents + leaf mask, 8 B child bases, 6·b/8 B per child
+	const int per = g_bits ? (24 + width * 6 * g_bits / 8 + 15) / 16 : (width * 16 + 15) / 16;
 	printf("%d-wide : %.1f visits (%.2f boxes each), %.2f triangle tests per ray -> %.0f requests (%d per visit), %.0f B of nodes\n", width, v4 / R,
 	       (double)boxes4 / v4, t4 / R, ((double)per * v4 + 5.0 * t4) / R, per, 16.0 * per * v4 / R);
 	return 0;
