@@ -28,11 +28,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
-# algorithmic work per traversal event: one node visit = two fp32 slab tests,
+# algorithmic work per traversal event: one node visit = the four fp32 slab tests of a 4-wide node,
 # one triangle test = the reference's Möller–Trumbore in fp64 (priced at 2 fp32-equivalents per flop)
-FLOP_NODE_VISIT = 46.0          # 2 boxes x (6 fma = 12 flop + 11 min/max)
+FLOP_NODE_VISIT = 87.0          # 4 boxes x (6 fma = 12 flop + 6 min/max) + per node 6 fma + 3 ldexp
 FLOP_TRI_TEST = 46.0 * 2.0
-BYTES_NODE, BYTES_TRI, BYTES_HIT = 32.0, 80.0, 24.0
+BYTES_NODE, BYTES_TRI, BYTES_HIT = 48.0, 80.0, 24.0
 
 
 def halton(i, b):

@@ -143,6 +143,33 @@ __device__ __forceinline__ bool slab(uint32_t wx, uint32_t wy, uint32_t wz, cons
 	return tn <= tf;
 }
 
+// One BINARY node step of a lane: fetch the node (2 × 16 B), test both children, go to the nearer hit child and push the
+// other one, or pop.  Returns the lane's next reference (inner node, raw leaf reference, or kSentinel).  Kept beside the
+// 4-wide step below for the form-factor kernel, whose lanes all start together and never refill: it is bound by
+// vector-ALU issue at decaying lane occupancy, and two cheap steps cost it less than one wide one (measured on the
+// 64 K-patch box: 8.7 against 8.2 G pair-samples/s).
+__device__ __forceinline__ int node_step(const SceneDev &S, const RayF &r, float tbest, int cur, int &sp, int *stack) {
+	const QNode *np = S.nodes + cur;
+	const uint4 a = np->a, b = np->b;
+	float t0, t1;
+	const bool h0 = slab(a.x, a.y, a.z, r, tbest, t0);
+	const bool h1 = slab(a.w, b.x, b.y, r, tbest, t1);
+	const int r0 = (int)b.z, r1 = (int)b.w;
+	if (h0 && h1) {
+		const bool swap = t1 < t0;
+		stack[sp * kBlock] = swap ? r0 : r1;
+		++sp;
+		return swap ? r1 : r0;
+	}
+	if (h0) return r0;
+	if (h1) return r1;
+	if (sp > 0) {
+		--sp;
+		return stack[sp * kBlock];
+	}
+	return kSentinel;
+}
+
 // ---------------------------------------------------------------- the 4-wide node step of the ray queries
 // t(plane) = (origin + q·2^e − (o ± pad))/d = q·(2^e/d) + (origin/d − (o ± pad)/d): 2^e/d is exact (v_ldexp_f32), the
 // addend costs one fused multiply-add per axis and side and node on the pre-rounded −(o ± pad)/d, then ONE fused
@@ -235,14 +262,25 @@ __device__ __forceinline__ uint32_t wave_slots() { // 64 on the first active lan
 
 struct HitP { double t; uint32_t pos; }; // pos: index into the leaf-ordered triangle array, RTMI_MISS = no hit (t = 0)
 
-template <bool ANY, bool COUNT = false>
+template <bool WIDE> struct StepRay;
+template <> struct StepRay<true> {
+	typedef RayW type;
+	static __device__ __forceinline__ RayW make(const SceneDev &S, double ox, double oy, double oz, double dx, double dy, double dz) { return make_rayw(S, ox, oy, oz, dx, dy, dz); }
+};
+template <> struct StepRay<false> {
+	typedef RayF type;
+	static __device__ __forceinline__ RayF make(const SceneDev &S, double ox, double oy, double oz, double dx, double dy, double dz) { return make_rayf(S, ox, oy, oz, dx, dy, dz); }
+};
+
+// WIDE = false walks the binary nodes (stack: rtmi_scene::stack_bytes_binary suffices), true the 4-wide ones.
+template <bool ANY, bool COUNT = false, bool WIDE = true>
 __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, double oz, double dx, double dy,
                                       double dz, double tmax, int *stack, HitP &h, Work *w = nullptr) {
 	h.t = 0.0;
 	h.pos = RTMI_MISS;
 	double best = tmax;
 	float tbest = f32_above(best);
-	const RayW r = make_rayw(S, ox, oy, oz, dx, dy, dz);
+	const typename StepRay<WIDE>::type r = StepRay<WIDE>::make(S, ox, oy, oz, dx, dy, dz);
 	int sp = 0;
 	int cur = S.root_ref;
 	uint32_t tk = 0, tend = 0;

@@ -10,7 +10,8 @@ struct rtmi_scene {
 	rtmi::SceneDev dev;
 	uint64_t n_tris;
 	int device;
-	uint32_t stack_bytes; // dynamic LDS of every traversal kernel: (BVH depth + 1) ints per lane
+	uint32_t stack_bytes;        // dynamic LDS of the traversal kernels: room for the deepest path of either hierarchy, ints per lane
+	uint32_t stack_bytes_binary; // ... of the kernels that walk the binary nodes only: (depth + 1) ints per lane
 	rtmi_scene_info info;
 	int *d_queue;                     // ring of work-queue counters, one per launch in flight (kQueueSlots)
 	std::atomic<uint32_t> next_slot;

@@ -63,7 +63,7 @@ __device__ __forceinline__ D3 sample_point(const double *__restrict__ e, uint64_
 // dir = Unit(xj − xi) and org = xi + 1e-5·dir are the caller's (the form-factor kernel reuses them).
 __device__ __forceinline__ bool visible_along(const SceneDev &S, const PatchesDev &P, uint32_t j, D3 org, D3 dir, D3 yi, int *stack) {
 	HitP h;
-	trace<false>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h);
+	trace<false, false, false>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h); // binary nodes, see node_step
 	if (h.pos == RTMI_MISS) return false;
 	// hit.point = o + (d·((v1 − o)·n)) / (n·d)   with the HIT triangle's first vertex and normal
 	const GTri &T = S.tris[h.pos];
@@ -82,7 +82,7 @@ __device__ __forceinline__ bool visible(const SceneDev &S, const PatchesDev &P, 
 RTMI_TRAVERSAL_KERNEL void k_visible_points(SceneDev S, PatchesDev P, uint64_t m,
                                                            const int32_t *__restrict__ ej, const double *__restrict__ xi,
                                                            const double *__restrict__ xj, uint8_t *__restrict__ vis) {
-	extern __shared__ int stack[]; // rtmi_scene::stack_bytes: (BVH depth + 1) entries per lane
+	extern __shared__ int stack[]; // rtmi_scene::stack_bytes_binary: (BVH depth + 1) entries per lane
 	const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	if (k >= m) return;
 	const D3 a = d3(xi[3 * k], xi[3 * k + 1], xi[3 * k + 2]), b = d3(xj[3 * k], xj[3 * k + 1], xj[3 * k + 2]);
@@ -101,7 +101,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDe
                                                          double cz, uint32_t samples, uint32_t light_samples,
                                                          uint64_t seed, uint32_t flags, uint32_t row0, uint32_t n_rows,
                                                          uint32_t n, float *__restrict__ F, uint64_t ld) {
-	extern __shared__ int stack_all[]; // rtmi_scene::stack_bytes
+	extern __shared__ int stack_all[]; // rtmi_scene::stack_bytes_binary
 	int *stack = stack_all + threadIdx.x;
 	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	if (idx >= (uint64_t)n_rows * n) return;
@@ -149,7 +149,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDe
 			const double tmp = ((1.0 / (4.0 * kPi)) * (dot(dir, ni) / (L * L)));
 			if (tmp > 0.0) { // only a positive term is ever added (:297-299): the ray is needed for those alone
 				HitP h;
-				trace<true>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h);
+				trace<true, false, false>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h);
 				if (h.pos == RTMI_MISS) ff += tmp;
 			}
 		}
@@ -656,7 +656,7 @@ int rtmi_visible_points(rtmi_patches *P, uint64_t m, const int32_t *ej, const do
 	     hipMemcpy(d_xj, xj, 24 * m, hipMemcpyHostToDevice) == hipSuccess;
 	int rc = ok ? 0 : fail(std::string(who) + ": device allocation or upload failed");
 	if (!rc) {
-		hipLaunchKernelGGL(k_visible_points, dim3((uint32_t)((m + kBlock - 1) / kBlock)), dim3(kBlock), P->scene->stack_bytes, nullptr,
+		hipLaunchKernelGGL(k_visible_points, dim3((uint32_t)((m + kBlock - 1) / kBlock)), dim3(kBlock), P->scene->stack_bytes_binary, nullptr,
 		                   P->scene->dev, pdev(P), m, d_ej, d_xi, d_xj, d_vis);
 		rc = launch_check(who);
 	}
@@ -683,7 +683,7 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 	if (grid > 0x7fffffffull) return fail(std::string(who) + ": too many entries for one launch; shard the rows");
 	const double cx = light_center ? light_center[0] : 0.0, cy = light_center ? light_center[1] : 0.0,
 	             cz = light_center ? light_center[2] : 0.0;
-	hipLaunchKernelGGL(k_form_factors, dim3((uint32_t)grid), dim3(kBlock), P->scene->stack_bytes, (hipStream_t)stream, P->scene->dev, pdev(P),
+	hipLaunchKernelGGL(k_form_factors, dim3((uint32_t)grid), dim3(kBlock), P->scene->stack_bytes_binary, (hipStream_t)stream, P->scene->dev, pdev(P),
 	                   light_center != nullptr, cx, cy, cz, samples, light_samples, seed, flags, row0, n_rows, n, d_F, ld);
 	return launch_check(who);
 }

@@ -223,7 +223,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	}
 	if (hipMalloc(&s->d_queue, kQueueSlots * sizeof(int)) != hipSuccess) { delete s; fail("rtmi_scene_create: hipMalloc failed"); return nullptr; }
 	// binary hierarchy (display pass): one push per inner node on a root-to-leaf path at most; the 4-wide one may need more
-	s->stack_bytes = (bvh.depth + 1u) * kBlock * (uint32_t)sizeof(int);
+	s->stack_bytes = s->stack_bytes_binary = (bvh.depth + 1u) * kBlock * (uint32_t)sizeof(int);
 	if (n == 0) return s;
 
 	// ---- the 4-wide hierarchy of the ray queries: collapse, lay out, quantise (WNode, rtmi_device.hpp) -------------
