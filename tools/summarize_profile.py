@@ -24,7 +24,7 @@ def short(name):
     return None
 
 
-lines = ["# rocprofv3 summary `%s` — `python3 bench.py --steps 5 --warmup 2 --no-cpu --ff-rows 32` on one MI355X" % tag, ""]
+lines = ["# rocprofv3 summary `%s` — `python3 bench.py --steps 5 --warmup 2 --no-cpu --ff-rows 256` on one MI355X" % tag, ""]
 lines += ["## --kernel-trace --stats (rtmi kernels; torch helper kernels that build the synthetic inputs omitted)", "",
           "| kernel | calls | avg ms | min ms | max ms | % of GPU time |", "|---|---|---|---|---|---|"]
 for row in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))):
