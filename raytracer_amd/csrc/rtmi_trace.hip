@@ -282,6 +282,10 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 				for (int a = 0; a < 3; ++a) {
 					const double ext = (double)x.hi[a] - (double)x.lo[a];
 					int e = -126;
+					if (ext > 0.0) {
+						(void)std::frexp(ext / 255.0, &e); // ext/255 = m·2^e, m in [0.5, 1)
+						e = std::max(e - 1, -126);
+					}
 					while (e < 127 && std::ldexp(255.0, e) < ext) ++e;
 					eb[a] = (uint32_t)(e & 0xff);
 					st[a] = std::ldexp(1.0, e);
