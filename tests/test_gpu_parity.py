@@ -217,6 +217,48 @@ def test_soup_closest_and_any_hit_vs_brute_force(rt, oracle, n_tris, n_rays):
         assert (tri >= 0).sum() > 1000
 
 
+@pytest.mark.parametrize("case", ["n2", "n3", "n4", "n6", "n7", "n9", "n17", "offset", "flat", "mixed_scales", "axis_rays"])
+def test_wide_node_layouts_vs_brute_force(rt, oracle, case):
+    """The 4-wide hierarchy's corner cases (rtmi_device.hpp WNode): nodes with 2 or 3 children, leaves beside inner
+    children, a grid origin far from 0, nodes of zero extent on an axis, children a million times smaller than their
+    node's 8-bit grid step, rays parallel to an axis.  Closest and any hit, bit for bit against the brute-force oracle."""
+    from raytracer_amd import workloads
+    rng = np.random.default_rng(11)
+    n_rays = 20000
+    o = rng.uniform(-1.5, 1.5, (n_rays, 3))
+    d = rng.normal(size=(n_rays, 3))
+    if case.startswith("n"):
+        tris = workloads.soup(int(case[1:]), seed=7, edge=0.5)
+    elif case == "offset":
+        tris = workloads.soup(500, seed=8, edge=0.3) + np.tile([4096.0, -8192.0, 1000.0], 3)
+        o += [4096.0, -8192.0, 1000.0]
+    elif case == "flat":
+        tris = workloads.soup(400, seed=9, edge=0.3)
+        tris[:, [2, 5, 8]] = 0.25                                   # every vertex in the plane z = 0.25
+    elif case == "mixed_scales":
+        small = workloads.soup(300, seed=10, edge=1e-5)
+        big = workloads.soup(20, seed=12, edge=50.0)
+        tris = np.concatenate([small, big])
+        aim = small[rng.integers(0, len(small), n_rays), 0:3] + rng.uniform(-2e-5, 2e-5, (n_rays, 3))
+        d = aim - o                                                 # aimed at the small triangles
+    else:
+        tris = workloads.soup(600, seed=13, edge=0.4)
+        ax = rng.integers(0, 3, n_rays)
+        d[:] = 0.0
+        d[np.arange(n_rays), ax] = rng.choice([-1.0, 1.0], n_rays)
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    tmax = np.where(rng.random(n_rays) < 0.5, 1e20, rng.uniform(0.1, 3.0, n_rays))
+    scene = rt.Scene(tris)
+    got = scene.Cast(rt.make_rays(o, d, tmax))
+    tri, t, u, v = oracle.closest_hit(tris, o, d, tmax)
+    assert np.array_equal(got["tri"], ids(tri))
+    assert np.array_equal(got["t"], t)
+    assert np.array_equal(got["u"], u.astype(np.float32)) and np.array_equal(got["v"], v.astype(np.float32))
+    assert np.array_equal(scene.Occluded(rt.make_rays(o, d, tmax)), oracle.any_hit(tris, o, d, tmax))
+    if case not in ("n2", "n3", "n4"):
+        assert (tri >= 0).sum() > 20
+
+
 def test_ties_on_shared_edges_and_duplicates(rt, oracle):
     """Rays aimed exactly at shared vertices / edges of a grid and at duplicated triangles: equal t ->
     smallest original id, as the reference's in-order scan (object.cpp:143-168)."""
