@@ -140,6 +140,12 @@ int rtmi_shadow_rays_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *
 int rtmi_ao_rays_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
                      uint32_t spp, double radius, uint64_t seed, rtmi_ray *d_out, void *stream);
 int rtmi_occlusion_fraction_dev(const uint8_t *d_occluded, uint64_t n, uint32_t spp, double *d_out, void *stream);
+/*   rtmi_ao_occlusion_dev  the whole loop of Shader::findOcclusionNew (Render2/shader.cpp:172-229) in one launch:
+ *                          d_occluded[k·spp + s] is byte for byte what rtmi_ao_rays_dev followed by rtmi_any_hit_dev
+ *                          writes, but the spp rays per hit are built inside the any-hit kernel and never stored
+ *                          (128 B of HBM traffic per ray less).  Misses give 0. */
+int rtmi_ao_occlusion_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                          uint32_t spp, double radius, uint64_t seed, uint8_t *d_occluded, void *stream);
 /*   rtmi_soft_shadow_rays_dev    Shader::generateSoftShadows (Render2/shader.cpp:41-103; the shipped Shade has its call
  *                          commented out, :475,521): n_points (reference: 100 = a 25 × 4 grid, :55-71) rays per hit toward
  *                          the grid through the light centre, origin P + 0.05·direction; ask rtmi_closest_hit_dev, then

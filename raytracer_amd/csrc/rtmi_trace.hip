@@ -33,6 +33,9 @@ __device__ __forceinline__ rtmi_hit hit_record(const SceneDev &S, const HitQ &h)
 
 // Rays from a buffer: the launch's waves work through rays [0, n) as ONE queue (a counter in device memory)
 // (trace_queue); callers that care about coherence sort the buffer first.
+#ifndef RTMI_AO_WAVES
+#define RTMI_AO_WAVES 4
+#endif
 template <bool ANY>
 RTMI_TRAVERSAL_KERNEL void k_trace_rays(SceneDev S, const rtmi_ray *__restrict__ rays,
                                                        uint64_t n, const uint32_t *__restrict__ d_n, uint32_t mul,
@@ -62,6 +65,38 @@ RTMI_TRAVERSAL_KERNEL void k_trace_rays(SceneDev S, const rtmi_ray *__restrict__
 		return false;
 	};
 	trace_queue<ANY, false, false>(S, stack + threadIdx.x, counter, items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
+}
+
+// Shader::findOcclusionNew (shader.cpp:140-232) in ONE launch: the ambient-occlusion ray of item k·spp + s is built in
+// the refill of the any-hit queue — hit point (object.cpp:23), hemisphere frame, square point of the stream
+// (seed, k, s), exactly the operations of k_ao_rays (rtmi_wavefront.hip) — and never exists in memory: 64 B written and
+// 64 B read per ray less than rtmi_ao_rays_dev + rtmi_any_hit_dev, same bytes out.
+RTMI_TRAVERSAL_KERNEL_W(RTMI_AO_WAVES) void k_ao_occlusion(SceneDev S, const double *__restrict__ v1_orig, const double *__restrict__ normals,
+                                             const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits, uint32_t n_items,
+                                             uint32_t spp, double radius, uint64_t seed, int *__restrict__ counter, Tune tune,
+                                             uint8_t *__restrict__ occluded) {
+	extern __shared__ int stack[];
+	auto fetch = [&](uint32_t idx, RayD &R) {
+		const uint32_t k = idx / spp, smp = idx % spp;
+		const rtmi_hit h = hits[k];
+		if (h.tri == RTMI_MISS) {
+			occluded[idx] = 0;
+			return false;
+		}
+		const D3 nrm = d3(normals[3 * (size_t)h.tri], normals[3 * (size_t)h.tri + 1], normals[3 * (size_t)h.tri + 2]);
+		const D3 P = hit_point(rays[k], v1_orig + 3 * (size_t)h.tri, nrm);
+		D3 org, dir;
+		ao_ray(P, nrm, radius, wf_mix64(wf_mix64(seed ^ (uint64_t)k) ^ (uint64_t)smp), org, dir);
+		R.ox = org.x; R.oy = org.y; R.oz = org.z;
+		R.dx = dir.x; R.dy = dir.y; R.dz = dir.z;
+		R.tmax = radius; // occluded ⇔ Cast ∧ distance < R (:226)
+		return true;
+	};
+	auto emit = [&](uint32_t idx, const HitQ &h, RayD &) {
+		occluded[idx] = h.pos != RTMI_MISS ? 1 : 0;
+		return false;
+	};
+	trace_queue<true, false, false>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
 }
 
 // Render2/rasterizer.cpp:230 — dir(i,j) = Unit(O + (j+sx)·dR − (i+sy)·dU), origin = eye.
@@ -506,6 +541,27 @@ int any_hit_counted(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t cap, const u
 	return trace_dev<true>(s, d_rays, cap, nullptr, d_occ, stream, who, d_n, mul);
 }
 
+static int ao_occlusion_dev(rtmi_scene *s, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n, uint32_t spp,
+                            double radius, uint64_t seed, uint8_t *d_occ, void *stream) {
+	const char *who = "rtmi_ao_occlusion_dev";
+	if (check_scene(s, who)) return -1;
+	if (n == 0 || spp == 0) return 0;
+	if (!d_normals || !d_rays || !d_hits || !d_occ) return fail(std::string(who) + ": NULL argument");
+	if (!(radius > 0.0)) return fail(std::string(who) + ": radius must be positive");
+	if (n * spp > 0xff000000ull) return fail(std::string(who) + ": too many rays for one launch");
+	if (s->n_tris == 0) { // nothing can be hit: every slot is a miss
+		if (hipMemsetAsync(d_occ, 0, n * spp, (hipStream_t)stream) != hipSuccess) return fail(std::string(who) + ": hipMemsetAsync failed");
+		return 0;
+	}
+	int *slot = queue_slot(s, (hipStream_t)stream, who);
+	if (!slot) return -1;
+	Tune tune = refill_threshold();
+	tune.thresh = (int)std::min(64u, env_uint("RTMI_REFILL_ANY", 32));
+	hipLaunchKernelGGL(k_ao_occlusion, dim3(persistent_grid(s, k_ao_occlusion, n * spp)), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev,
+	                   s->d_v1_orig, d_normals, d_rays, d_hits, (uint32_t)(n * spp), spp, radius, seed, slot, tune, d_occ);
+	return launch_check(who);
+}
+
 // host-pointer convenience wrappers: stage through device buffers, synchronous
 template <bool ANY>
 static int trace_host(rtmi_scene *s, const rtmi_ray *rays, uint64_t n, rtmi_hit *out, uint8_t *occ, const char *who) {
@@ -572,6 +628,11 @@ int rtmi_any_hit(rtmi_scene *s, const rtmi_ray *rays, uint64_t n, uint8_t *occlu
 }
 int rtmi_any_hit_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, uint8_t *d_occluded, void *stream) {
 	return trace_dev<true>(s, d_rays, n, nullptr, d_occluded, stream, "rtmi_any_hit_dev");
+}
+
+int rtmi_ao_occlusion_dev(rtmi_scene *s, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n, uint32_t spp,
+                          double radius, uint64_t seed, uint8_t *d_occluded, void *stream) {
+	return ao_occlusion_dev(s, d_normals, d_rays, d_hits, n, spp, radius, seed, d_occluded, stream);
 }
 
 int rtmi_triangle_intersection(uint64_t n, const double *o, const double *d, const double *tri, double *t, double *u,

@@ -72,6 +72,11 @@ def test_ao_wavefront_room(rt, oracle):
     f.scene.ao_rays_dev(f.normals.data_ptr(), f.rays.data_ptr(), f.hits.data_ptr(), f.n, spp, R, seed, out.data_ptr(), f.st)
     occ = torch.zeros(f.n * spp, dtype=torch.uint8, device="cuda")
     f.scene.occluded_dev(out.data_ptr(), f.n * spp, occ.data_ptr(), f.st)
+    # the fused launch (rays built inside the any-hit kernel) writes the same bytes
+    occ_fused = torch.full((f.n * spp,), 7, dtype=torch.uint8, device="cuda")
+    f.scene.ao_occlusion_dev(f.normals.data_ptr(), f.rays.data_ptr(), f.hits.data_ptr(), f.n, spp, R, seed, occ_fused.data_ptr(), f.st)
+    torch.cuda.synchronize()
+    assert torch.equal(occ, occ_fused)
     frac = torch.zeros(f.n, dtype=torch.float64, device="cuda")
     rt.occlusion_fraction_dev(occ.data_ptr(), f.n, spp, frac.data_ptr(), f.st)
     torch.cuda.synchronize()

@@ -42,3 +42,13 @@ t = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
 print("C4 room %d tris, %dx%d, %d AO spp: primary %.2f ms (%.0f Mrays/s) | AO gen %.2f ms | AO any-hit %.2f ms (%.0f Mrays/s) | shadow gen+any-hit %.2f ms | reduce %.2f ms | frame %.2f ms = %.0f Mrays/s overall; AO mean %.3f shadowed %.3f" % (
     len(tris), cam.x_res, cam.y_res, spp, t[0], n / t[0] / 1e3, t[1], t[2], n * spp / t[2] / 1e3, t[3], t[4], sum(t),
     n * (spp + 2) / sum(t) / 1e3, float(frac.mean()), float(socc.float().mean())), flush=True)
+# the same AO bytes from the fused launch (rays built in the any-hit kernel's refill)
+occ2 = torch.zeros_like(occ)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+scene.ao_occlusion_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, spp, 2.0, 1, occ2.data_ptr(), st); torch.cuda.synchronize()
+e0.record()
+scene.ao_occlusion_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, spp, 2.0, 1, occ2.data_ptr(), st)
+e1.record(); torch.cuda.synchronize()
+tf = e0.elapsed_time(e1)
+print("   fused AO (rtmi_ao_occlusion_dev): %.2f ms against %.2f ms for generate + any-hit (%.0f Mrays/s); same bytes: %s; frame %.2f ms" % (
+    tf, t[1] + t[2], n * spp / tf / 1e3, bool(torch.equal(occ, occ2)), sum(t) - t[1] - t[2] + tf), flush=True)
