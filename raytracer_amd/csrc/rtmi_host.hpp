@@ -33,4 +33,8 @@ int closest_hit_counted(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t cap, con
                         void *stream, const char *who);
 int any_hit_counted(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t cap, const uint32_t *d_n, uint32_t mul, uint8_t *d_occ,
                     void *stream, const char *who);
+// for queue kernels (trace_queue) defined in other translation units: a zeroed counter of the scene's ring, and the
+// size of a persistent grid for `kernel` (workgroups of kBlock threads, rtmi_scene::stack_bytes of dynamic LDS)
+int *queue_slot(rtmi_scene *s, hipStream_t st, const char *who);
+uint32_t persistent_grid_of(rtmi_scene *s, const void *kernel, uint64_t n_items);
 } // namespace rtmi

@@ -285,12 +285,21 @@ __global__ void __launch_bounds__(kReserveBlock) k_ao_list(const uint32_t *__res
 	}
 }
 
-// findOcclusionNew's rays (shader.cpp:140-232), spp per listed node: one thread per node (hit point and hemisphere
-// frame once), rays at[·spp + s].  Square points: stream (mix64(seed ^ path), root ray index, sample).
-__global__ void __launch_bounds__(256) k_node_ao_rays(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
-                                                      const Node *__restrict__ nodes, const uint32_t *__restrict__ ao_slot,
-                                                      const uint32_t *__restrict__ ao_count, const uint64_t *__restrict__ root,
-                                                      uint32_t spp, double R, uint64_t seed, rtmi_ray *__restrict__ out) {
+// findOcclusionNew (shader.cpp:140-232) for the listed nodes, in two launches and without the rays in memory:
+// k_node_ao_frames — one thread per node: hit point, hemisphere frame (:153-171) and the node's sample stream
+//                    (mix64(seed ^ path), root ray index), 112 B per node;
+// k_ao_trace       — any-hit queue over (node, sample) items; a lane builds its ray from the node's frame and the square
+//                    point of (stream, sample) when it refills (:177-220), traces it with tmax = R (:226) and writes
+//                    the byte at[·spp + s].  Whole waves refill: building a ray costs more than reading one.
+struct __attribute__((aligned(16))) AoFrame {
+	double P[3], X[3], Y[3], Z[3];
+	uint64_t stream, pad;
+};
+
+__global__ void __launch_bounds__(256) k_node_ao_frames(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
+                                                        const Node *__restrict__ nodes, const uint32_t *__restrict__ ao_slot,
+                                                        const uint32_t *__restrict__ ao_count, const uint64_t *__restrict__ root,
+                                                        uint64_t seed, AoFrame *__restrict__ out) {
 	const uint64_t count = *ao_count;
 	RTMI_FOR_ITEMS(at, in, count) {
 		if (!in) continue;
@@ -300,13 +309,37 @@ __global__ void __launch_bounds__(256) k_node_ao_rays(ShadeDev S, const rtmi_ray
 		const D3 P = hit_point(rays[k], S.v1_orig + 3 * (size_t)h.tri, Ns);
 		D3 X, Y, Z;
 		ao_frame(Ns, X, Y, Z);
-		const uint64_t stream = wf_mix64(wf_mix64(seed ^ (uint64_t)nodes[k].path) ^ root[nodes[k].rootslot]);
-		for (uint32_t s = 0; s < spp; ++s) {
-			D3 org, dir;
-			ao_ray_in_frame(P, X, Y, Z, R, wf_mix64(stream ^ (uint64_t)s), org, dir);
-			set_ray(out[at * spp + s], org, dir, R); // occluded ⇔ Cast ∧ distance < R (:226)
-		}
+		AoFrame f;
+		f.P[0] = P.x; f.P[1] = P.y; f.P[2] = P.z;
+		f.X[0] = X.x; f.X[1] = X.y; f.X[2] = X.z;
+		f.Y[0] = Y.x; f.Y[1] = Y.y; f.Y[2] = Y.z;
+		f.Z[0] = Z.x; f.Z[1] = Z.y; f.Z[2] = Z.z;
+		f.stream = wf_mix64(wf_mix64(seed ^ (uint64_t)nodes[k].path) ^ root[nodes[k].rootslot]);
+		f.pad = 0;
+		out[at] = f;
 	}
+}
+
+RTMI_TRAVERSAL_KERNEL_W(4) void k_ao_trace(SceneDev scene, const AoFrame *__restrict__ frames, const uint32_t *__restrict__ ao_count,
+                                           uint64_t cap_items, uint32_t spp, double R, int *__restrict__ counter, Tune tune,
+                                           uint8_t *__restrict__ occ) {
+	extern __shared__ int stack[];
+	const uint32_t items = (uint32_t)min((unsigned long long)cap_items, (unsigned long long)*ao_count * spp);
+	auto fetch = [&](uint32_t idx, RayD &Q) {
+		const uint32_t at = idx / spp, smp = idx % spp;
+		const AoFrame &f = frames[at];
+		D3 org, dir;
+		ao_ray_in_frame(ld(f.P), ld(f.X), ld(f.Y), ld(f.Z), R, wf_mix64(f.stream ^ (uint64_t)smp), org, dir);
+		Q.ox = org.x; Q.oy = org.y; Q.oz = org.z;
+		Q.dx = dir.x; Q.dy = dir.y; Q.dz = dir.z;
+		Q.tmax = R;
+		return true;
+	};
+	auto emit = [&](uint32_t idx, const HitQ &h, RayD &) {
+		occ[idx] = h.pos != RTMI_MISS ? 1 : 0;
+		return false;
+	};
+	trace_queue<true, false, false>(scene, stack + threadIdx.x, counter, items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
 }
 
 // The colour of an opaque hit (shader.cpp:481-522) and its reflected child (:527-537, :643).
@@ -467,7 +500,8 @@ struct Chunk {
 	std::vector<rtmi_ray *> rays;
 	std::vector<Node *> nodes;
 	rtmi_hit *hits;
-	rtmi_ray *shadow, *ao;
+	rtmi_ray *shadow;
+	AoFrame *ao;
 	uint8_t *shadowed, *ao_occ, *wants_ao;
 	uint32_t *ao_slot, *ao_at;
 	uint64_t *root;
@@ -484,7 +518,7 @@ static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t 
 	// bytes per generation-1 ray at capacity
 	double per = 8.0, s = 1.0, smax = 1.0;
 	for (uint32_t g = 0; g < levels; ++g) { per += s * (sizeof(rtmi_ray) + sizeof(Node)); smax = s; s *= c.branch; }
-	per += smax * (sizeof(rtmi_hit) + sizeof(rtmi_ray) + 2 + 8 + (double)c.spp * (sizeof(rtmi_ray) + 1));
+	per += smax * (sizeof(rtmi_hit) + sizeof(rtmi_ray) + 2 + 8 + (c.spp ? sizeof(AoFrame) + (double)c.spp : 0.0));
 	const double budget = (double)env_uint("RTMI_SHADE_WS_MB", 8192) * 1048576.0;
 	uint64_t cap = (uint64_t)(budget / per);
 	cap = std::max<uint64_t>(256, cap & ~(uint64_t)255);
@@ -506,7 +540,7 @@ static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t 
 	}
 	const uint64_t mx = c.slots[levels - 1];
 	const size_t o_hits = take(mx * sizeof(rtmi_hit)), o_sh = take(mx * sizeof(rtmi_ray)), o_shb = take(mx);
-	const size_t o_ao = take(c.spp ? mx * c.spp * sizeof(rtmi_ray) : 0), o_aob = take(c.spp ? mx * c.spp : 0);
+	const size_t o_ao = take(c.spp ? mx * sizeof(AoFrame) : 0), o_aob = take(c.spp ? mx * c.spp : 0);
 	const size_t o_aos = take(c.spp ? mx * sizeof(uint32_t) : 0), o_aoat = take(c.spp ? mx * sizeof(uint32_t) : 0), o_want = take(mx);
 	const size_t o_root = take(cap * sizeof(uint64_t));
 	const size_t o_counts = take((2 * levels + 2) * sizeof(uint32_t));
@@ -520,7 +554,7 @@ static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t 
 	c.hits = (rtmi_hit *)(sh->ws + o_hits);
 	c.shadow = (rtmi_ray *)(sh->ws + o_sh);
 	c.shadowed = (uint8_t *)(sh->ws + o_shb);
-	c.ao = (rtmi_ray *)(sh->ws + o_ao);
+	c.ao = (AoFrame *)(sh->ws + o_ao);
 	c.ao_occ = (uint8_t *)(sh->ws + o_aob);
 	c.ao_slot = (uint32_t *)(sh->ws + o_aos);
 	c.ao_at = (uint32_t *)(sh->ws + o_aoat);
@@ -548,9 +582,14 @@ static int run_chunk(rtmi_shader *sh, const Chunk &c, uint64_t n, const rtmi_tra
 		if (c.spp) {
 			hipLaunchKernelGGL(k_ao_list, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, cnt, c.wants_ao, c.shadowed, c.ao_at, ao_cnt,
 			                   c.ao_slot);
-			hipLaunchKernelGGL(k_node_ao_rays, grid_for(sh, cap), dim3(256), 0, st, S, c.rays[g], c.hits, c.nodes[g], c.ao_slot, ao_cnt,
-			                   c.root, c.spp, p.ao_radius, p.seed, c.ao);
-			if (any_hit_counted(sh->scene, c.ao, cap * c.spp, ao_cnt, c.spp, c.ao_occ, st, who)) return -1;
+			hipLaunchKernelGGL(k_node_ao_frames, grid_for(sh, cap), dim3(256), 0, st, S, c.rays[g], c.hits, c.nodes[g], c.ao_slot, ao_cnt,
+			                   c.root, p.seed, c.ao);
+			int *slot = queue_slot(sh->scene, st, who);
+			if (!slot) return -1;
+			Tune tune = refill_threshold();
+			tune.thresh = (int)std::min(64u, env_uint("RTMI_REFILL_AO", 64));
+			hipLaunchKernelGGL(k_ao_trace, dim3(persistent_grid_of(sh->scene, reinterpret_cast<const void *>(k_ao_trace), cap * c.spp)), dim3(kBlock),
+			                   sh->scene->stack_bytes, st, sh->scene->dev, c.ao, ao_cnt, cap * c.spp, c.spp, p.ao_radius, slot, tune, c.ao_occ);
 		}
 		hipLaunchKernelGGL(k_shade_post, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, S, c.rays[g], c.hits, cnt, last, c.spp,
 		                   c.shadowed, c.ao_at, c.ao_occ, c.nodes[g], kid_cnt, kid_rays, kid_nodes);
