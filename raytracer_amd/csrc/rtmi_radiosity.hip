@@ -95,7 +95,7 @@ RTMI_TRAVERSAL_KERNEL void k_visible_points(SceneDev S, PatchesDev P, uint64_t m
 //   j == n_patches (light) : Render2/radiosity.cpp:264-303 (findFormFactorTermWithLight)
 //   i == n_patches or i == j : 0   (:382, :391-393)
 #ifndef RTMI_FF_WAVES
-#define RTMI_FF_WAVES 6
+#define RTMI_FF_WAVES 7
 #endif
 RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDev P, bool has_light, double cx, double cy,
                                                          double cz, uint32_t samples, uint32_t light_samples,
