@@ -124,6 +124,13 @@ int rtmi_primary_work_dev(rtmi_scene *, const rtmi_camera *cam, double sx, doubl
 int rtmi_any_hit(rtmi_scene *, const rtmi_ray *rays, uint64_t n, uint8_t *occluded);
 int rtmi_any_hit_dev(rtmi_scene *, const rtmi_ray *d_rays, uint64_t n, uint8_t *d_occluded, void *stream);
 
+/* Host only, no GPU needed (tests): builds the hierarchies rtmi_scene_create would build for these triangles and checks
+ * every invariant the kernels rely on — each child box of the 4-wide nodes, decoded as the kernels decode it, contains
+ * the child's fp32 bounds; references in range; every triangle reachable exactly once; the stack bound holds on every
+ * path.  stats = {violations, 4-wide nodes, stack entries needed, depth of the binary hierarchy}.  No reference
+ * counterpart (the reference's BSP, scene.cpp:463-693, is replaced). */
+int rtmi_debug_check_hierarchy(const double *tri_xyz, uint64_t n_tris, uint64_t stats[4]);
+
 /* ---- wavefront: secondary rays generated on the device -----------------------------------------------
  * The batch producers between two ray-query calls, so that a frame's hit records never leave HBM:
  * d_rays[k] produced d_hits[k]; d_normals = n_tris × 3 doubles, the reference's triNormal per ORIGINAL triangle

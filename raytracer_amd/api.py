@@ -75,7 +75,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_
 SYMBOLS = [
     "rtmi_last_error", "rtmi_device_count", "rtmi_triangle_intersection", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_get_info",
     "rtmi_closest_hit", "rtmi_closest_hit_dev", "rtmi_camera_setup", "rtmi_primary_closest_hit_dev",
-    "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev",
+    "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev", "rtmi_debug_check_hierarchy",
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev",
     "rtmi_shader_create", "rtmi_shader_destroy", "rtmi_trace_dev", "rtmi_render_frame_dev", "rtmi_tone_map_dev",
@@ -115,6 +115,7 @@ def _load():
     L.rtmi_shadow_rays_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
     L.rtmi_ao_rays_dev.argtypes = [vp, vp, vp, vp, u64, u32, dbl, u64, vp, vp]
     L.rtmi_ao_occlusion_dev.argtypes = [vp, vp, vp, vp, u64, u32, dbl, u64, vp, vp]
+    L.rtmi_debug_check_hierarchy.argtypes = [vp, u64, vp]
     L.rtmi_occlusion_fraction_dev.argtypes = [vp, u64, u32, vp, vp]
     L.rtmi_soft_shadow_rays_dev.argtypes = [vp, vp, vp, vp, u64, vp, u32, vp, vp]
     L.rtmi_soft_shadow_factor_dev.argtypes = [vp, vp, u64, u32, vp, vp]
@@ -189,6 +190,15 @@ def triangle_intersection(o, d, v0, v1, v2, u0=0.0, v0_=0.0):
     t = np.zeros(n); u = np.full(n, float(u0)); v = np.full(n, float(v0_))
     _check(lib.rtmi_triangle_intersection(n, _ptr(o), _ptr(d), _ptr(tri), _ptr(t), _ptr(u), _ptr(v)))
     return t, u, v
+
+
+def check_hierarchy(tri_xyz):
+    """Host only: builds the hierarchies of Scene(tri_xyz) and checks the invariants the kernels rely on.
+    Returns (violations, wide_nodes, stack_entries, binary_depth)."""
+    t = _np(tri_xyz, np.float64, (-1, 9))
+    stats = np.zeros(4, np.uint64)
+    _check(lib.rtmi_debug_check_hierarchy(_ptr(t), len(t), _ptr(stats)))
+    return tuple(int(v) for v in stats)
 
 
 def BuildScene(scenes_dir, stem):

@@ -1,5 +1,6 @@
 // Binned-SAH BVH2 builder (host, multi-threaded).  See bvh_build.hpp.
 #include "bvh_build.hpp"
+#include <string>
 
 #include <algorithm>
 #include <atomic>
@@ -198,6 +199,194 @@ Bvh2 build_bvh2(const double *xyz, uint64_t n, uint32_t max_leaf, uint32_t max_d
 	std::memcpy(out.lo, out.nodes[0].lo, sizeof out.lo);
 	std::memcpy(out.hi, out.nodes[0].hi, sizeof out.hi);
 	return out;
+}
+
+int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err) {
+	// A node adopts grandchildren, always opening the inner child with the largest surface area, until it has four
+	// children or only leaves.  Inner children first (consecutive node slots), then the leaves (consecutive triangle
+	// positions); nodes in depth-first order.
+	out.nodes.clear();
+	out.build_of.clear();
+	out.leaf_pos.assign(bvh.nodes.size(), 0u);
+	out.stack_need = 0;
+	if (bvh.nodes.empty()) return 0;
+	auto area = [&](int32_t i) {
+		const BuildNode &x = bvh.nodes[i];
+		const float d0 = x.hi[0] - x.lo[0], d1 = x.hi[1] - x.lo[1], d2 = x.hi[2] - x.lo[2];
+		return d0 * d1 + d1 * d2 + d0 * d2;
+	};
+	uint32_t next_tri = 0;
+	if (bvh.nodes[0].left < 0) {
+		if (bvh.nodes[0].count != 1) { err = "a leaf with more than one triangle"; return -1; }
+		out.leaf_pos[0] = next_tri++;
+		return 0;
+	}
+	struct Item { uint32_t build_id, out_id; };
+	std::vector<Item> todo;
+	std::vector<uint32_t> kids_of; // per wide node: n_children | n_inner << 4 (for the stack bound below)
+	out.nodes.reserve(bvh.nodes.size() / 3 + 1);
+	out.nodes.emplace_back();
+	todo.push_back({0u, 0u});
+	while (!todo.empty()) {
+		const Item it = todo.back();
+		todo.pop_back();
+		const BuildNode &x = bvh.nodes[it.build_id];
+		int32_t kid[4] = {x.left, x.right, -1, -1};
+		int nk = 2;
+		while (nk < 4) {
+			int best = -1;
+			float ba = -1.f;
+			for (int k = 0; k < nk; ++k)
+				if (bvh.nodes[kid[k]].left >= 0 && area(kid[k]) > ba) { ba = area(kid[k]); best = k; }
+			if (best < 0) break;
+			const BuildNode &c = bvh.nodes[kid[best]];
+			kid[best] = c.left;
+			kid[nk++] = c.right;
+		}
+		std::stable_partition(kid, kid + nk, [&](int32_t k) { return bvh.nodes[k].left >= 0; });
+		int ni = 0;
+		while (ni < nk && bvh.nodes[kid[ni]].left >= 0) ++ni;
+		const uint32_t inner_base = (uint32_t)out.nodes.size(), tri_base = next_tri;
+		for (int k = 0; k < ni; ++k) out.nodes.emplace_back();
+		for (int k = ni - 1; k >= 0; --k) todo.push_back({(uint32_t)kid[k], inner_base + (uint32_t)k}); // child 0 is laid out next
+		for (int k = ni; k < nk; ++k) {
+			if (bvh.nodes[kid[k]].count != 1) { err = "a leaf with more than one triangle"; return -1; }
+			out.leaf_pos[kid[k]] = next_tri++;
+		}
+		// the node's grid: origin = its lo corner, step 2^e with 255·2^e >= extent (e as a signed byte)
+		uint32_t eb[3];
+		double st[3];
+		for (int a = 0; a < 3; ++a) {
+			const double ext = (double)x.hi[a] - (double)x.lo[a];
+			int e = -126;
+			if (ext > 0.0) {
+				(void)std::frexp(ext / 255.0, &e); // ext/255 = m·2^e, m in [0.5, 1)
+				e = std::max(e - 1, -126);
+			}
+			while (e < 127 && std::ldexp(255.0, e) < ext) ++e;
+			eb[a] = (uint32_t)(e & 0xff);
+			st[a] = std::ldexp(1.0, e);
+		}
+		uint32_t w[6] = {0, 0, 0, 0, 0, 0}; // lo.x, hi.x, lo.y, hi.y, lo.z, hi.z: one byte per child
+		for (int k = 0; k < nk; ++k) {
+			const BuildNode &c = bvh.nodes[kid[k]];
+			for (int a = 0; a < 3; ++a) {
+				// origin + q·2^e is exact in double (q <= 255): the quantised box contains the fp32 box
+				double ql = std::floor(((double)c.lo[a] - (double)x.lo[a]) / st[a]);
+				double qh = std::ceil(((double)c.hi[a] - (double)x.lo[a]) / st[a]);
+				ql = std::min(255.0, std::max(0.0, ql));
+				qh = std::min(255.0, std::max(0.0, qh));
+				while (ql > 0.0 && (double)x.lo[a] + ql * st[a] > (double)c.lo[a]) ql -= 1.0;
+				while (qh < 255.0 && (double)x.lo[a] + qh * st[a] < (double)c.hi[a]) qh += 1.0;
+				w[2 * a] |= (uint32_t)ql << (8 * k);
+				w[2 * a + 1] |= (uint32_t)qh << (8 * k);
+			}
+		}
+		auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+		WideNode g;
+		g.w[0] = fbits(x.lo[0]); g.w[1] = fbits(x.lo[1]); g.w[2] = fbits(x.lo[2]);
+		g.w[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)ni << 24) | ((uint32_t)nk << 28);
+		for (int q = 0; q < 6; ++q) g.w[4 + q] = w[q];
+		g.w[10] = inner_base;
+		g.w[11] = ~((tri_base - (uint32_t)ni) << 3);
+		out.nodes[it.out_id] = g;
+		if (out.build_of.size() < out.nodes.size()) out.build_of.resize(out.nodes.size(), 0u);
+		out.build_of[it.out_id] = it.build_id;
+		if (kids_of.size() < out.nodes.size()) kids_of.resize(out.nodes.size(), 0u);
+		kids_of[it.out_id] = (uint32_t)nk | ((uint32_t)ni << 4);
+	}
+	// stack bound: on the way down a node leaves at most n_children − 1 entries behind; children have larger indices
+	std::vector<uint32_t> need(out.nodes.size(), 0u);
+	for (size_t i = out.nodes.size(); i-- > 0;) {
+		const uint32_t nk = kids_of[i] & 15u, ni = kids_of[i] >> 4, base = out.nodes[i].w[10];
+		uint32_t below = 0;
+		for (uint32_t k = 0; k < ni; ++k) below = std::max(below, need[base + k]);
+		need[i] = nk - 1u + below;
+	}
+	out.stack_need = need[0];
+	if (next_tri != bvh.order.size()) { err = "internal error: the 4-wide layout lost triangles"; return -1; }
+	return 0;
+}
+
+uint64_t check_wide(const Bvh2 &bvh, const Wide4 &wide) {
+	uint64_t bad = 0;
+	const uint64_t n = bvh.order.size();
+	if (n == 0) return wide.nodes.empty() ? 0 : 1;
+	// every leaf of the binary hierarchy owns one position, all positions distinct
+	std::vector<uint8_t> used(n, 0);
+	std::vector<int32_t> leaf_at(n, -1); // position -> build node
+	for (size_t i = 0; i < bvh.nodes.size(); ++i)
+		if (bvh.nodes[i].left < 0) {
+			const uint32_t pos = wide.leaf_pos[i];
+			if (pos >= n || used[pos]) { ++bad; continue; }
+			used[pos] = 1;
+			leaf_at[pos] = (int32_t)i;
+		}
+	for (uint64_t k = 0; k < n; ++k) bad += used[k] ? 0 : 1;
+	if (wide.nodes.empty()) return bad + (bvh.nodes[0].left < 0 ? 0 : 1);
+	if (wide.build_of.size() != wide.nodes.size()) return bad + 1;
+	// walk the wide hierarchy beside the binary one: a wide node stands for a binary inner node
+	struct Item { uint32_t wide_id; int32_t build_id; uint32_t above; };
+	std::vector<Item> todo = {{0u, 0, 0u}};
+	std::vector<uint8_t> seen_pos(n, 0);
+	uint64_t visited = 0;
+	while (!todo.empty()) {
+		const Item it = todo.back();
+		todo.pop_back();
+		++visited;
+		const WideNode &g = wide.nodes[it.wide_id];
+		const BuildNode &x = bvh.nodes[it.build_id];
+		float org[3];
+		std::memcpy(org, g.w, 12);
+		const uint32_t ni = (g.w[3] >> 24) & 15u, nk = g.w[3] >> 28;
+		if (nk < 2 || nk > 4 || ni > nk) { ++bad; continue; }
+		if (it.above + nk - 1 > wide.stack_need) ++bad;
+		double st[3];
+		for (int a = 0; a < 3; ++a) {
+			if (org[a] != x.lo[a]) ++bad;
+			st[a] = std::ldexp(1.0, (int)(int8_t)((g.w[3] >> (8 * a)) & 0xffu));
+		}
+		// a child stands for a descendant of x at most three levels down (the collapse opens at most two nodes in a row)
+		int32_t cand[14];
+		int nc = 0;
+		cand[nc++] = x.left; cand[nc++] = x.right;
+		for (int q = 0; q < nc && nc + 2 <= 14; ++q)
+			if (bvh.nodes[cand[q]].left >= 0) { cand[nc++] = bvh.nodes[cand[q]].left; cand[nc++] = bvh.nodes[cand[q]].right; }
+		auto is_near_descendant = [&](int32_t b) {
+			for (int q = 0; q < nc; ++q)
+				if (cand[q] == b) return true;
+			return false;
+		};
+		for (uint32_t k = 0; k < nk; ++k) {
+			double lo[3], hi[3];
+			for (int a = 0; a < 3; ++a) {
+				lo[a] = (double)org[a] + (double)((g.w[4 + 2 * a] >> (8 * k)) & 0xffu) * st[a];
+				hi[a] = (double)org[a] + (double)((g.w[5 + 2 * a] >> (8 * k)) & 0xffu) * st[a];
+			}
+			int32_t child_build = -1;
+			if (k < ni) {
+				const uint32_t cid = g.w[10] + k;
+				if (cid >= wide.nodes.size() || cid <= it.wide_id) { ++bad; continue; }
+				const int32_t want = (int32_t)wide.build_of[cid];
+				if (is_near_descendant(want) && bvh.nodes[want].left >= 0) child_build = want;
+				if (child_build < 0) { ++bad; continue; }
+				todo.push_back({cid, child_build, it.above + nk - 1});
+			} else {
+				const uint32_t ref = g.w[11] - (k << 3); // ~(pos << 3)
+				const uint32_t pos = (~ref) >> 3;
+				if (((~ref) & 7u) != 0 || pos >= n || leaf_at[pos] < 0 || seen_pos[pos]) { ++bad; continue; }
+				seen_pos[pos] = 1;
+				child_build = leaf_at[pos];
+				if (!is_near_descendant(child_build)) ++bad;
+			}
+			const BuildNode &c = bvh.nodes[child_build];
+			for (int a = 0; a < 3; ++a)
+				if (!(lo[a] <= (double)c.lo[a] && hi[a] >= (double)c.hi[a])) ++bad;
+		}
+	}
+	for (uint64_t k = 0; k < n; ++k) bad += seen_pos[k] ? 0 : 1; // every triangle reachable
+	if (visited != wide.nodes.size()) ++bad;
+	return bad;
 }
 
 } // namespace rtmi

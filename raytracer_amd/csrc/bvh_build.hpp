@@ -6,6 +6,7 @@
 // reference's dead abvh.cpp: AABB hierarchy + surface-area cost, Render2/abvh.cpp:242-304).
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace rtmi {
@@ -29,5 +30,23 @@ struct Bvh2 {
 // max_depth bounds the traversal stack: once the remaining depth budget only just fits a balanced
 // tree, splits fall back to the object median.
 Bvh2 build_bvh2(const double *xyz, uint64_t n, uint32_t max_leaf, uint32_t max_depth, unsigned n_threads);
+
+// The 4-wide hierarchy of the ray queries, in the device's node format (rtmi_device.hpp: WNode, twelve 32-bit words):
+//   w[0..2] origin (float bits)   w[3] ex | ey<<8 | ez<<16 (signed bytes) | n_inner<<24 | n_children<<28
+//   w[4..9] lo.x, hi.x, lo.y, hi.y, lo.z, hi.z: one byte per child      w[10] index of inner child 0
+//   w[11]   ~(first << 3), first = position of the triangle of child 0 if it were a leaf: child k's leaf reference is w[11] − 8k
+struct WideNode { uint32_t w[12]; };
+struct Wide4 {
+	std::vector<WideNode> nodes;    // nodes[0] = root; empty when the binary root is a leaf
+	std::vector<uint32_t> leaf_pos; // per binary build node: position of a leaf's triangle in the device's triangle array
+	std::vector<uint32_t> build_of; // per wide node: the binary inner node it stands for
+	uint32_t stack_need = 0;        // entries the deepest root-to-leaf path can leave on the traversal stack
+};
+// Collapses a binary hierarchy whose leaves hold ONE triangle each.  Returns 0, or -1 with a message.
+int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err);
+// Host-side check of every invariant the kernels rely on (tests): each child's box, decoded as the kernels decode it,
+// contains the child's fp32 box; references are in range; every triangle position is used exactly once; stack_need
+// bounds every path.  Returns the number of violations.
+uint64_t check_wide(const Bvh2 &bvh, const Wide4 &wide);
 
 } // namespace rtmi

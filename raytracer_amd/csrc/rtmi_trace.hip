@@ -261,106 +261,16 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	s->stack_bytes = s->stack_bytes_binary = (bvh.depth + 1u) * kBlock * (uint32_t)sizeof(int);
 	if (n == 0) return s;
 
-	// ---- the 4-wide hierarchy of the ray queries: collapse, lay out, quantise (WNode, rtmi_device.hpp) -------------
-	// A node adopts grandchildren, always opening the inner child with the largest surface area, until it has four
-	// children or only leaves.  Inner children first (consecutive node slots), then the leaves (consecutive triangle
-	// positions); nodes in depth-first order.  leaf_pos[build node] = position of a leaf's triangle.
-	std::vector<uint32_t> leaf_pos(bvh.nodes.size(), 0u);
-	std::vector<WNode> wnodes;
-	uint32_t wide_need = 0; // stack entries the deepest path of the 4-wide hierarchy can hold
+	// ---- the 4-wide hierarchy of the ray queries: collapse, lay out, quantise (bvh_build.cpp: build_wide) ----------
+	Wide4 wide;
 	{
-		auto area = [&](int32_t i) {
-			const BuildNode &x = bvh.nodes[i];
-			const float d0 = x.hi[0] - x.lo[0], d1 = x.hi[1] - x.lo[1], d2 = x.hi[2] - x.lo[2];
-			return d0 * d1 + d1 * d2 + d0 * d2;
-		};
-		uint32_t next_tri = 0;
-		if (bvh.nodes[0].left < 0) {
-			if (bvh.nodes[0].count != 1) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: a leaf with more than one triangle"); return nullptr; }
-			leaf_pos[0] = next_tri++;
-		} else {
-			struct Item { uint32_t build_id, out_id; };
-			std::vector<Item> todo;
-			std::vector<uint32_t> kids_of; // per wide node: n_children | first inner child << 4 (for the stack bound below)
-			wnodes.reserve(bvh.nodes.size() / 3 + 1);
-			wnodes.emplace_back();
-			todo.push_back({0u, 0u});
-			while (!todo.empty()) {
-				const Item it = todo.back();
-				todo.pop_back();
-				const BuildNode &x = bvh.nodes[it.build_id];
-				int32_t kid[4] = {x.left, x.right, -1, -1};
-				int nk = 2;
-				while (nk < 4) {
-					int best = -1;
-					float ba = -1.f;
-					for (int k = 0; k < nk; ++k)
-						if (bvh.nodes[kid[k]].left >= 0 && area(kid[k]) > ba) { ba = area(kid[k]); best = k; }
-					if (best < 0) break;
-					const BuildNode &c = bvh.nodes[kid[best]];
-					kid[best] = c.left;
-					kid[nk++] = c.right;
-				}
-				std::stable_partition(kid, kid + nk, [&](int32_t k) { return bvh.nodes[k].left >= 0; });
-				int ni = 0;
-				while (ni < nk && bvh.nodes[kid[ni]].left >= 0) ++ni;
-				const uint32_t inner_base = (uint32_t)wnodes.size(), tri_base = next_tri;
-				for (int k = 0; k < ni; ++k) wnodes.emplace_back();
-				for (int k = ni - 1; k >= 0; --k) todo.push_back({(uint32_t)kid[k], inner_base + (uint32_t)k}); // child 0 is laid out next
-				for (int k = ni; k < nk; ++k) {
-					if (bvh.nodes[kid[k]].count != 1) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: a leaf with more than one triangle"); return nullptr; }
-					leaf_pos[kid[k]] = next_tri++;
-				}
-				// the node's grid: origin = its lo corner, step 2^e with 255·2^e >= extent (e as a signed byte)
-				uint32_t eb[3];
-				double st[3];
-				for (int a = 0; a < 3; ++a) {
-					const double ext = (double)x.hi[a] - (double)x.lo[a];
-					int e = -126;
-					if (ext > 0.0) {
-						(void)std::frexp(ext / 255.0, &e); // ext/255 = m·2^e, m in [0.5, 1)
-						e = std::max(e - 1, -126);
-					}
-					while (e < 127 && std::ldexp(255.0, e) < ext) ++e;
-					eb[a] = (uint32_t)(e & 0xff);
-					st[a] = std::ldexp(1.0, e);
-				}
-				uint32_t w[6] = {0, 0, 0, 0, 0, 0}; // lo.x, hi.x, lo.y, hi.y, lo.z, hi.z: one byte per child
-				for (int k = 0; k < nk; ++k) {
-					const BuildNode &c = bvh.nodes[kid[k]];
-					for (int a = 0; a < 3; ++a) {
-						// origin + q·2^e is exact in double (q <= 255): the quantised box contains the fp32 box
-						double ql = std::floor(((double)c.lo[a] - (double)x.lo[a]) / st[a]);
-						double qh = std::ceil(((double)c.hi[a] - (double)x.lo[a]) / st[a]);
-						ql = std::min(255.0, std::max(0.0, ql));
-						qh = std::min(255.0, std::max(0.0, qh));
-						while (ql > 0.0 && (double)x.lo[a] + ql * st[a] > (double)c.lo[a]) ql -= 1.0;
-						while (qh < 255.0 && (double)x.lo[a] + qh * st[a] < (double)c.hi[a]) qh += 1.0;
-						w[2 * a] |= (uint32_t)ql << (8 * k);
-						w[2 * a + 1] |= (uint32_t)qh << (8 * k);
-					}
-				}
-				auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-				WNode g;
-				g.a = make_uint4(fbits(x.lo[0]), fbits(x.lo[1]), fbits(x.lo[2]), eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)ni << 24) | ((uint32_t)nk << 28));
-				g.b = make_uint4(w[0], w[1], w[2], w[3]);
-				g.c = make_uint4(w[4], w[5], inner_base, ~((tri_base - (uint32_t)ni) << 3));
-				wnodes[it.out_id] = g;
-				if (kids_of.size() < wnodes.size()) kids_of.resize(wnodes.size(), 0u);
-				kids_of[it.out_id] = (uint32_t)nk | ((uint32_t)ni << 4);
-			}
-			// stack bound: on the way down a node leaves at most n_children − 1 entries behind; children have larger indices
-			std::vector<uint32_t> need(wnodes.size(), 0u);
-			for (size_t i = wnodes.size(); i-- > 0;) {
-				const uint32_t nk = kids_of[i] & 15u, ni = kids_of[i] >> 4, base = wnodes[i].c.z;
-				uint32_t below = 0;
-				for (uint32_t k = 0; k < ni; ++k) below = std::max(below, need[base + k]);
-				need[i] = nk - 1u + below;
-			}
-			wide_need = need[0];
-		}
-		if (next_tri != n) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: internal error: the 4-wide layout lost triangles"); return nullptr; }
+		std::string err;
+		if (build_wide(bvh, wide, err)) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: " + err); return nullptr; }
 	}
+	static_assert(sizeof(WideNode) == sizeof(WNode), "host and device layout of the 4-wide node");
+	const std::vector<uint32_t> &leaf_pos = wide.leaf_pos;
+	const std::vector<WideNode> &wnodes = wide.nodes;
+	const uint32_t wide_need = wide.stack_need;
 	if ((wide_need + 1u) * kBlock * sizeof(int) > 64u * 1024u) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: BVH deeper than the traversal stack"); return nullptr; }
 	s->stack_bytes = (std::max(bvh.depth, wide_need) + 1u) * kBlock * (uint32_t)sizeof(int);
 	if (env_uint("RTMI_VERBOSE", 0))
@@ -631,6 +541,22 @@ int rtmi_closest_hit_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, rtmi
 int rtmi_any_hit(rtmi_scene *s, const rtmi_ray *rays, uint64_t n, uint8_t *occluded) {
 	return trace_host<true>(s, rays, n, nullptr, occluded, "rtmi_any_hit");
 }
+int rtmi_debug_check_hierarchy(const double *tri_xyz, uint64_t n_tris, uint64_t stats[4]) {
+	const char *who = "rtmi_debug_check_hierarchy";
+	if ((n_tris > 0 && !tri_xyz) || !stats) return fail(std::string(who) + ": NULL argument");
+	if (n_tris >= kMaxFirst) return fail(std::string(who) + ": more than 2^27-1 triangles");
+	const unsigned threads = std::min(env_uint("RTMI_BUILD_THREADS", std::max(1u, std::thread::hardware_concurrency())), 16u);
+	Bvh2 bvh = build_bvh2(tri_xyz, n_tris, 1, kStackDepth - 2, threads);
+	Wide4 wide;
+	std::string err;
+	if (build_wide(bvh, wide, err)) return fail(std::string(who) + ": " + err);
+	stats[0] = check_wide(bvh, wide);
+	stats[1] = wide.nodes.size();
+	stats[2] = wide.stack_need;
+	stats[3] = bvh.depth;
+	return 0;
+}
+
 int rtmi_any_hit_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, uint8_t *d_occluded, void *stream) {
 	return trace_dev<true>(s, d_rays, n, nullptr, d_occluded, stream, "rtmi_any_hit_dev");
 }

@@ -1,0 +1,24 @@
+// Host-only test program (tests/test_host_abi.py compiles it against raytracer_amd/csrc/bvh_build.cpp): the hierarchy
+// checker behind rtmi_debug_check_hierarchy must accept the builder's output and catch every single-field corruption.
+#include <cstdio>
+#include <random>
+#include "bvh_build.hpp"
+using namespace rtmi;
+int main() {
+	std::mt19937_64 g(1); std::uniform_real_distribution<double> U(-1, 1), E(-0.05, 0.05);
+	const uint64_t n = 5000; std::vector<double> xyz(9 * n);
+	for (uint64_t i = 0; i < n; ++i) { double c[3] = {U(g), U(g), U(g)}; for (int a = 0; a < 3; ++a) { xyz[9*i+a] = c[a]; xyz[9*i+3+a] = c[a] + E(g); xyz[9*i+6+a] = c[a] + E(g); } }
+	Bvh2 b = build_bvh2(xyz.data(), n, 1, 30, 4);
+	Wide4 w; std::string err;
+	if (build_wide(b, w, err)) { printf("err %s\n", err.c_str()); return 1; }
+	if (check_wide(b, w) != 0) { printf("FAIL clean\n"); return 1; }
+	// mutations
+	{ Wide4 m = w; m.nodes[10].w[5] -= 1; if (check_wide(b, m) == 0) { printf("FAIL hi.x byte of child 0 lowered\n"); return 1; } }
+	{ Wide4 m = w; m.nodes[7].w[4] += 0x100; if (check_wide(b, m) == 0) { printf("FAIL lo.x byte of child 1 raised\n"); return 1; } }
+	{ Wide4 m = w; m.nodes[3].w[10] += 1; if (check_wide(b, m) == 0) { printf("FAIL inner base shifted\n"); return 1; } }
+	{ Wide4 m = w; m.nodes[20].w[11] -= 8; if (check_wide(b, m) == 0) { printf("FAIL leaf base shifted\n"); return 1; } }
+	{ Wide4 m = w; m.stack_need -= 1; if (check_wide(b, m) == 0) { printf("FAIL stack bound too small\n"); return 1; } }
+	{ Wide4 m = w; m.nodes[5].w[3] -= 1; if (check_wide(b, m) == 0) { printf("FAIL x exponent lowered\n"); return 1; } }
+	printf("ok\n");
+	return 0;
+}

@@ -190,3 +190,49 @@ def test_scene_file_reader_errors(tmp_path):
     (tmp_path / "thing.obj").write_text("o thing\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nf 1 2 4 3\nf 1 2 9\n")
     with pytest.raises(rt.RtmiError, match="does not exist"):
         rt.BuildScene(str(tmp_path), "b")
+
+
+@pytest.mark.parametrize("case", ["n1", "n2", "n3", "n5", "n64", "soup20k", "offset", "flat", "mixed_scales", "grid", "duplicates"])
+def test_hierarchy_invariants_on_the_host(case):
+    """rtmi_debug_check_hierarchy (host only): the binary + 4-wide hierarchies rtmi_scene_create builds keep every
+    invariant the kernels rely on — child boxes decoded as the kernels decode them contain the children's fp32 bounds,
+    every triangle is reachable exactly once, the LDS stack bound covers every path."""
+    import raytracer_amd as rt
+    from raytracer_amd import workloads
+    rng = np.random.default_rng(3)
+    if case.startswith("n"):
+        tris = workloads.soup(int(case[1:]), seed=2, edge=0.3)
+    elif case == "soup20k":
+        tris = workloads.soup(20000, seed=4, edge=0.02)
+    elif case == "offset":
+        tris = workloads.soup(3000, seed=5, edge=0.1) + np.tile([1.0e5, -3.0e4, 7.0e3], 3)
+    elif case == "flat":
+        tris = workloads.soup(2000, seed=6, edge=0.2)
+        tris[:, [1, 4, 7]] = -2.5
+    elif case == "mixed_scales":
+        tris = np.concatenate([workloads.soup(2000, seed=7, edge=1e-6), workloads.soup(50, seed=8, edge=200.0)])
+    elif case == "grid":
+        tris = workloads.closed_box(12)[0]
+    else:
+        t = workloads.soup(300, seed=9, edge=0.2)
+        tris = np.concatenate([t, t, t])
+    bad, wide_nodes, need, depth = rt.check_hierarchy(tris)
+    n = len(tris)
+    assert bad == 0
+    assert (wide_nodes == 0) == (n == 1)
+    if n > 1:
+        assert (n - 1 + 2) // 3 <= wide_nodes <= n - 1           # between all-4-wide and all-binary
+        assert need <= 3 * depth and need + 1 <= 64              # fits the dynamic LDS of a 256-lane workgroup
+
+
+def test_hierarchy_checker_catches_corruptions(tmp_path):
+    """tests/cpp/wide_mutations.cpp: the checker accepts the builder's output and flags a lowered hi byte, a raised lo
+    byte, shifted child bases, a stack bound one too small and a lowered grid exponent."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "wide_mutations")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(root, "raytracer_amd", "csrc"),
+                    os.path.join(root, "tests", "cpp", "wide_mutations.cpp"), os.path.join(root, "raytracer_amd", "csrc", "bvh_build.cpp"),
+                    "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
