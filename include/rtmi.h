@@ -60,8 +60,8 @@ typedef struct rtmi_camera {
 typedef struct rtmi_scene rtmi_scene;
 
 typedef struct rtmi_scene_info {
-	uint64_t n_tris, n_nodes, n_leaves;
-	uint32_t max_depth, max_leaf_size;
+	uint64_t n_tris, n_nodes, n_leaves; /* nodes, leaves and depth of the binary hierarchy (the 4-wide one of the ray */
+	uint32_t max_depth, max_leaf_size;  /* queries is its collapse; a leaf holds one triangle); device_bytes covers both */
 	double build_seconds;
 	uint64_t device_bytes;
 	float scene_lo[3], scene_hi[3];
@@ -82,7 +82,8 @@ int rtmi_triangle_intersection(uint64_t n, const double *o, const double *d, con
  * Replaces Scene::BuildBSP (Render2/scene.cpp:463-479, 528-693).  tri_xyz: n_tris × 9 doubles
  * (triVert1, triVert2, triVert3) in Scene::sceneObjects / Object::triangles order — that order IS
  * the triangle id.  tri_object (may be NULL = all 0): index into sceneObjects.  Builds a binned-SAH
- * BVH on the host, flattens it, uploads to the current device. */
+ * BVH on the host (one triangle per leaf), collapses it into the 4-wide nodes the ray queries walk, and uploads both
+ * to the current device. */
 rtmi_scene *rtmi_scene_create(const double *tri_xyz, const uint32_t *tri_object, uint64_t n_tris);
 void rtmi_scene_destroy(rtmi_scene *);
 int rtmi_scene_get_info(const rtmi_scene *, rtmi_scene_info *out);
