@@ -99,6 +99,24 @@ __device__ __forceinline__ double mt_exact(double ox, double oy, double oz, doub
 	return ((e2x * qx) + (e2y * qy) + (e2z * qz)) * inv_det;
 }
 
+// A triangle record in exactly FIVE aligned 16-byte loads issued together.  (Reading the fields one by one, the compiler
+// fetched overlapping pieces — six loads — and sank those of v0 behind the det window test: a second, dependent memory
+// round trip in every triangle step.)
+__device__ __forceinline__ GTri load_tri(const GTri *p) {
+	typedef double d2 __attribute__((ext_vector_type(2)));
+	const d2 *q = reinterpret_cast<const d2 *>(p);
+	const d2 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+	asm volatile("" : : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e));
+	GTri T;
+	T.v0[0] = a.x; T.v0[1] = a.y; T.v0[2] = b.x;
+	T.e1[0] = b.y; T.e1[1] = c.x; T.e1[2] = c.y;
+	T.e2[0] = d.x; T.e2[1] = d.y; T.e2[2] = e.x;
+	const unsigned long long w = (unsigned long long)__double_as_longlong(e.y);
+	T.orig = (uint32_t)w;
+	T.object = (uint32_t)(w >> 32);
+	return T;
+}
+
 // ---------------------------------------------------------------- conservative fp32 slab test
 // The boxes only steer; the exact test decides.  They must never cull a triangle the exact test
 // would accept, so every slab is widened per ray by pad = 2^-18·(scene |coord| max + |o|max), which
@@ -302,7 +320,7 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 			}
 		} else if (cur == kLeaf) {
 			if (COUNT) { ++w->tests; w->test_slots += wave_slots(); }
-			const GTri T = S.tris[tk];
+			const GTri T = load_tri(S.tris + tk);
 			double u = 0.0, v = 0.0;
 			const double t = mt_exact(ox, oy, oz, dx, dy, dz, T, u, v);
 			bool done = false;
@@ -466,7 +484,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 		} else {
 			if (cur == kLeaf) {
 				if (COUNT) { ++w->tests; w->test_slots += wave_slots(); }
-				const GTri T = S.tris[tk]; // the whole 80-B record in one round trip
+				const GTri T = load_tri(S.tris + tk); // the whole 80-B record in one round trip
 				double u = 0.0, v = 0.0;
 				const double t = mt_exact(UNIFORM_O ? uox : R.ox, UNIFORM_O ? uoy : R.oy, UNIFORM_O ? uoz : R.oz, R.dx, R.dy, R.dz, T, u, v);
 				bool done = false;
