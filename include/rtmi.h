@@ -163,6 +163,12 @@ int rtmi_soft_shadow_rays_dev(rtmi_scene *, const double *d_normals, const rtmi_
                               const double light_center[3], uint32_t n_points, rtmi_ray *d_out, void *stream);
 int rtmi_soft_shadow_factor_dev(const rtmi_hit *d_hits, const rtmi_hit *d_shadow_hits, uint64_t n, uint32_t n_points,
                                 double *d_out, void *stream);
+/*   rtmi_soft_shadow_dev  the same three steps in one launch + a reduction: the n_points rays per hit are built inside the
+ *                          closest-hit kernel and never stored (the 3-step path moves 88 B per ray through HBM twice: 17 GB
+ *                          for a 1920×1080 frame at n_points = 100); d_contrib (n · n_points bytes, workspace of the caller)
+ *                          receives 1 per contributing ray, d_factor what rtmi_soft_shadow_factor_dev returns, bit for bit. */
+int rtmi_soft_shadow_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                         const double light_center[3], uint32_t n_points, uint8_t *d_contrib, double *d_factor, void *stream);
 
 /* ---- frame: Scene::Trace + Shader::Shade as a wavefront -------------------------------------------------
  * Replaces the recursion Scene::Trace (Render2/scene.cpp:127-155) -> Shader::Shade (Render2/shader.cpp:395-645, the

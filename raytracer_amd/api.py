@@ -79,7 +79,7 @@ SYMBOLS = [
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev",
     "rtmi_shader_create", "rtmi_shader_destroy", "rtmi_trace_dev", "rtmi_render_frame_dev", "rtmi_tone_map_dev",
-    "rtmi_raster_setup", "rtmi_render_frame_sampled_dev", "rtmi_soft_shadow_rays_dev", "rtmi_soft_shadow_factor_dev",
+    "rtmi_raster_setup", "rtmi_render_frame_sampled_dev", "rtmi_soft_shadow_rays_dev", "rtmi_soft_shadow_factor_dev", "rtmi_soft_shadow_dev",
     "rtmi_scene_file_load", "rtmi_scene_file_free", "rtmi_scene_file_info", "rtmi_scene_file_get",
     "rtmi_radiosity_trace_dev", "rtmi_radiosity_raster_dev", "rtmi_tone_map_radiosity_dev",
 ]
@@ -119,6 +119,7 @@ def _load():
     L.rtmi_occlusion_fraction_dev.argtypes = [vp, u64, u32, vp, vp]
     L.rtmi_soft_shadow_rays_dev.argtypes = [vp, vp, vp, vp, u64, vp, u32, vp, vp]
     L.rtmi_soft_shadow_factor_dev.argtypes = [vp, vp, u64, u32, vp, vp]
+    L.rtmi_soft_shadow_dev.argtypes = [vp, vp, vp, vp, u64, vp, u32, vp, vp, vp]
     L.rtmi_patches_create.restype = vp
     L.rtmi_patches_create.argtypes = [vp, vp, vp]
     L.rtmi_patches_destroy.argtypes = [vp]
@@ -328,6 +329,11 @@ class Scene:
     def ao_rays_dev(self, d_normals, d_rays, d_hits, n, spp, radius, seed, d_out, stream=0):
         """Shader::findOcclusionNew's rays (shader.cpp:140-232), spp per hit record."""
         _check(lib.rtmi_ao_rays_dev(self.handle, d_normals, d_rays, d_hits, n, spp, float(radius), seed, d_out, stream))
+
+    def soft_shadow_dev(self, d_normals, d_rays, d_hits, n, light_center, n_points, d_contrib, d_factor, stream=0):
+        """Shader::generateSoftShadows for a batch of hit records in one launch (+ reduction): the factor per hit."""
+        lc = _np(light_center, np.float64, (3,))
+        _check(lib.rtmi_soft_shadow_dev(self.handle, d_normals, d_rays, d_hits, n, _ptr(lc), n_points, d_contrib, d_factor, stream))
 
     def ao_occlusion_dev(self, d_normals, d_rays, d_hits, n, spp, radius, seed, d_occluded, stream=0):
         """The loop of Shader::findOcclusionNew in one launch: ao_rays_dev + occluded_dev without the rays in memory."""

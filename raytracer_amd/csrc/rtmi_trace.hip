@@ -99,6 +99,49 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_AO_WAVES) void k_ao_occlusion(SceneDev S, const dou
 	trace_queue<true, false, false>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
 }
 
+// Shader::generateSoftShadows (shader.cpp:41-103) in one launch, like k_ao_occlusion: the ray of item k·n_points + i·divY + j
+// toward grid point (i, j) through the light centre (:60-71, :90-91) is built in the refill of a closest-hit queue, and
+// only its verdict is stored: 1 iff it hits a triangle of ANOTHER object than the shaded hit's (:93-100).  The operations
+// are those of k_soft_shadow_rays + k_soft_shadow_factor (rtmi_wavefront.hip).
+RTMI_TRAVERSAL_KERNEL_W(RTMI_AO_WAVES) void k_soft_shadow(SceneDev S, const double *__restrict__ v1_orig, const double *__restrict__ normals,
+                                            const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits, uint32_t n_items,
+                                            uint32_t n_points, uint32_t div_x, uint32_t div_y, double cx, double cy, double cz,
+                                            int *__restrict__ counter, Tune tune, uint8_t *__restrict__ contrib) {
+	extern __shared__ int stack[];
+	auto fetch = [&](uint32_t idx, RayD &R) {
+		const uint32_t k = idx / n_points, smp = idx % n_points;
+		const rtmi_hit h = hits[k];
+		if (h.tri == RTMI_MISS) {
+			contrib[idx] = 0;
+			return false;
+		}
+		const D3 nrm = d3(normals[3 * (size_t)h.tri], normals[3 * (size_t)h.tri + 1], normals[3 * (size_t)h.tri + 2]);
+		const D3 P = hit_point(rays[k], v1_orig + 3 * (size_t)h.tri, nrm);
+		const uint32_t i = smp / div_y, j = smp % div_y;
+		const D3 target = d3(cx - 1 + ((j * 2 + 1) / (double)div_y), cy - 1 + ((i * 2 + 1) / (double)div_x), cz); // :69
+		const D3 dir = unit(target - P);
+		const D3 org = P + (0.05 * dir);
+		R.ox = org.x; R.oy = org.y; R.oz = org.z;
+		R.dx = dir.x; R.dy = dir.y; R.dz = dir.z;
+		R.tmax = RTMI_INFINITY;
+		return true;
+	};
+	auto emit = [&](uint32_t idx, const HitQ &h, RayD &) {
+		contrib[idx] = (h.pos != RTMI_MISS && S.tris[h.pos].object != hits[idx / n_points].object) ? 1 : 0;
+		return false;
+	};
+	trace_queue<false, false, false>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
+}
+
+// factor = 1 − contributors / n_points, 1 when there is none (shader.cpp:100-102)
+__global__ void k_soft_shadow_reduce(const uint8_t *__restrict__ contrib, uint64_t n, uint32_t n_points, double *__restrict__ out) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	int c = 0;
+	for (uint32_t s = 0; s < n_points; ++s) c += contrib[k * n_points + s];
+	out[k] = c > 0 ? (1.0 - ((double)c) / ((double)n_points)) : 1.0;
+}
+
 // Render2/rasterizer.cpp:230 — dir(i,j) = Unit(O + (j+sx)·dR − (i+sy)·dU), origin = eye.
 __device__ __forceinline__ D3 primary_dir(const rtmi_camera &c, uint32_t i, uint32_t j, double sx, double sy) {
 	const D3 O = d3(c.O[0], c.O[1], c.O[2]), dR = d3(c.dR[0], c.dR[1], c.dR[2]), dU = d3(c.dU[0], c.dU[1], c.dU[2]);
@@ -477,6 +520,32 @@ static int ao_occlusion_dev(rtmi_scene *s, const double *d_normals, const rtmi_r
 	return launch_check(who);
 }
 
+static int soft_shadow_dev(rtmi_scene *s, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                           const double light_center[3], uint32_t n_points, uint8_t *d_contrib, double *d_factor, void *stream) {
+	const char *who = "rtmi_soft_shadow_dev";
+	if (check_scene(s, who)) return -1;
+	if (n == 0) return 0;
+	if (!d_normals || !d_rays || !d_hits || !light_center || !d_contrib || !d_factor || n_points == 0)
+		return fail(std::string(who) + ": NULL argument or n_points == 0");
+	if (n * n_points > 0xff000000ull) return fail(std::string(who) + ": too many rays for one launch");
+	hipStream_t st = (hipStream_t)stream;
+	if (s->n_tris == 0) {
+		if (hipMemsetAsync(d_contrib, 0, n * n_points, st) != hipSuccess) return fail(std::string(who) + ": hipMemsetAsync failed");
+	} else {
+		int *slot = queue_slot(s, st, who);
+		if (!slot) return -1;
+		uint32_t div_x = n_points, div_y = 1; // shader.cpp:60-63
+		while (div_x % 2 == 0) { div_x /= 2; div_y *= 2; }
+		Tune tune = refill_threshold();
+		tune.thresh = (int)std::min(64u, env_uint("RTMI_REFILL_SOFT", 48)); // C4 room, 52 M rays: 4.76 / 4.20 / 4.00 / 4.04 ms at 16 / 32 / 48 / 64
+		hipLaunchKernelGGL(k_soft_shadow, dim3(persistent_grid(s, k_soft_shadow, n * n_points)), dim3(kBlock), s->stack_bytes, st, s->dev, s->d_v1_orig,
+		                   d_normals, d_rays, d_hits, (uint32_t)(n * n_points), n_points, div_x, div_y, light_center[0], light_center[1],
+		                   light_center[2], slot, tune, d_contrib);
+	}
+	hipLaunchKernelGGL(k_soft_shadow_reduce, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d_contrib, n, n_points, d_factor);
+	return launch_check(who);
+}
+
 // host-pointer convenience wrappers: stage through device buffers, synchronous
 template <bool ANY>
 static int trace_host(rtmi_scene *s, const rtmi_ray *rays, uint64_t n, rtmi_hit *out, uint8_t *occ, const char *who) {
@@ -541,6 +610,11 @@ int rtmi_closest_hit_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, rtmi
 int rtmi_any_hit(rtmi_scene *s, const rtmi_ray *rays, uint64_t n, uint8_t *occluded) {
 	return trace_host<true>(s, rays, n, nullptr, occluded, "rtmi_any_hit");
 }
+int rtmi_soft_shadow_dev(rtmi_scene *s, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                         const double light_center[3], uint32_t n_points, uint8_t *d_contrib, double *d_factor, void *stream) {
+	return soft_shadow_dev(s, d_normals, d_rays, d_hits, n, light_center, n_points, d_contrib, d_factor, stream);
+}
+
 int rtmi_debug_check_hierarchy(const double *tri_xyz, uint64_t n_tris, uint64_t stats[4]) {
 	const char *who = "rtmi_debug_check_hierarchy";
 	if ((n_tris > 0 && !tri_xyz) || !stats) return fail(std::string(who) + ": NULL argument");

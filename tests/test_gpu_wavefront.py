@@ -164,3 +164,12 @@ def test_soft_shadow_wavefront_studio(rt, oracle):
     assert np.array_equal(fac.cpu().numpy()[k], s["factor"])
     miss = h["tri"] == rt.MISS
     assert np.all(sr["reserved"][miss] != 0) and np.all(fac.cpu().numpy()[miss] == 1.0)
+    # the fused launch (rays built inside the closest-hit kernel): the same factors, and the per-ray verdicts
+    contrib = torch.full((n * NP,), 9, dtype=torch.uint8, device="cuda")
+    fac2 = torch.full((n,), -1.0, dtype=torch.float64, device="cuda")
+    scene.soft_shadow_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, g["lights"][0, :3], NP, contrib.data_ptr(), fac2.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(fac, fac2)
+    sh = shits.cpu().numpy().view(rt.HIT_DTYPE).reshape(n, NP)
+    want = (sh["tri"] != rt.MISS) & (sh["object"] != h["object"][:, None]) & ~miss[:, None]
+    assert np.array_equal(contrib.cpu().numpy().reshape(n, NP), want.astype(np.uint8))

@@ -52,3 +52,18 @@ e1.record(); torch.cuda.synchronize()
 tf = e0.elapsed_time(e1)
 print("   fused AO (rtmi_ao_occlusion_dev): %.2f ms against %.2f ms for generate + any-hit (%.0f Mrays/s); same bytes: %s; frame %.2f ms" % (
     tf, t[1] + t[2], n * spp / tf / 1e3, bool(torch.equal(occ, occ2)), sum(t) - t[1] - t[2] + tf), flush=True)
+# soft shadows (BASELINE config 4 names them; the shipped Shade has the call commented out): 100 rays per hit, 3 steps vs fused
+NP = 100
+m = n // 4                                         # a quarter of the frame: the 3-step path needs 88 B per ray
+srays = torch.zeros(m * NP * 64, dtype=torch.uint8, device="cuda"); shits = torch.zeros(m * NP * 24, dtype=torch.uint8, device="cuda")
+fac = torch.zeros(m, dtype=torch.float64, device="cuda"); fac2 = torch.zeros_like(fac); contrib = torch.zeros(m * NP, dtype=torch.uint8, device="cuda")
+def three():
+    scene.soft_shadow_rays_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), m, light, NP, srays.data_ptr(), st)
+    scene.cast_dev(srays.data_ptr(), m * NP, shits.data_ptr(), stream=st)
+    rt.soft_shadow_factor_dev(hits.data_ptr(), shits.data_ptr(), m, NP, fac.data_ptr(), st)
+def fused():
+    scene.soft_shadow_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), m, light, NP, contrib.data_ptr(), fac2.data_ptr(), st)
+for f in (three, fused):
+    f(); torch.cuda.synchronize(); e0.record(); f(); e1.record(); torch.cuda.synchronize()
+    print("   soft shadows, %d hits x %d rays, %s: %.2f ms (%.0f Mrays/s)" % (m, NP, f.__name__, e0.elapsed_time(e1), m * NP / e0.elapsed_time(e1) / 1e3), flush=True)
+print("   same factors: %s; mean factor %.3f" % (bool(torch.equal(fac, fac2)), float(fac.mean())), flush=True)
