@@ -201,7 +201,7 @@ Bvh2 build_bvh2(const double *xyz, uint64_t n, uint32_t max_leaf, uint32_t max_d
 	return out;
 }
 
-int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err) {
+int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err, unsigned n_threads) {
 	// A node adopts grandchildren, always opening the inner child with the largest surface area, until it has four
 	// children or only leaves.  Inner children first (consecutive node slots), then the leaves (consecutive triangle
 	// positions); nodes in depth-first order.
@@ -221,90 +221,114 @@ int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err) {
 		out.leaf_pos[0] = next_tri++;
 		return 0;
 	}
+	// 1. the layout (sequential, cheap): which binary nodes become 4-wide nodes, their children, node slots, triangle positions
+	struct Plan { uint32_t build_id; int32_t kid[4]; uint32_t nk, ni, inner_base, tri_base; };
+	std::vector<Plan> plan;
+	plan.reserve(bvh.nodes.size() / 3 + 1);
 	struct Item { uint32_t build_id, out_id; };
 	std::vector<Item> todo;
-	std::vector<uint32_t> kids_of; // per wide node: n_children | n_inner << 4 (for the stack bound below)
-	out.nodes.reserve(bvh.nodes.size() / 3 + 1);
-	out.nodes.emplace_back();
+	plan.emplace_back();
 	todo.push_back({0u, 0u});
 	while (!todo.empty()) {
 		const Item it = todo.back();
 		todo.pop_back();
 		const BuildNode &x = bvh.nodes[it.build_id];
-		int32_t kid[4] = {x.left, x.right, -1, -1};
+		Plan p;
+		p.build_id = it.build_id;
+		p.kid[0] = x.left; p.kid[1] = x.right; p.kid[2] = p.kid[3] = -1;
 		int nk = 2;
 		while (nk < 4) {
 			int best = -1;
 			float ba = -1.f;
 			for (int k = 0; k < nk; ++k)
-				if (bvh.nodes[kid[k]].left >= 0 && area(kid[k]) > ba) { ba = area(kid[k]); best = k; }
+				if (bvh.nodes[p.kid[k]].left >= 0 && area(p.kid[k]) > ba) { ba = area(p.kid[k]); best = k; }
 			if (best < 0) break;
-			const BuildNode &c = bvh.nodes[kid[best]];
-			kid[best] = c.left;
-			kid[nk++] = c.right;
+			const BuildNode &c = bvh.nodes[p.kid[best]];
+			p.kid[best] = c.left;
+			p.kid[nk++] = c.right;
 		}
-		std::stable_partition(kid, kid + nk, [&](int32_t k) { return bvh.nodes[k].left >= 0; });
+		std::stable_partition(p.kid, p.kid + nk, [&](int32_t k) { return bvh.nodes[k].left >= 0; });
 		int ni = 0;
-		while (ni < nk && bvh.nodes[kid[ni]].left >= 0) ++ni;
-		const uint32_t inner_base = (uint32_t)out.nodes.size(), tri_base = next_tri;
-		for (int k = 0; k < ni; ++k) out.nodes.emplace_back();
-		for (int k = ni - 1; k >= 0; --k) todo.push_back({(uint32_t)kid[k], inner_base + (uint32_t)k}); // child 0 is laid out next
+		while (ni < nk && bvh.nodes[p.kid[ni]].left >= 0) ++ni;
+		p.nk = (uint32_t)nk; p.ni = (uint32_t)ni;
+		p.inner_base = (uint32_t)plan.size();
+		p.tri_base = next_tri;
+		for (int k = 0; k < ni; ++k) plan.emplace_back();
+		for (int k = ni - 1; k >= 0; --k) todo.push_back({(uint32_t)p.kid[k], p.inner_base + (uint32_t)k}); // child 0 is laid out next
 		for (int k = ni; k < nk; ++k) {
-			if (bvh.nodes[kid[k]].count != 1) { err = "a leaf with more than one triangle"; return -1; }
-			out.leaf_pos[kid[k]] = next_tri++;
+			if (bvh.nodes[p.kid[k]].count != 1) { err = "a leaf with more than one triangle"; return -1; }
+			out.leaf_pos[p.kid[k]] = next_tri++;
 		}
-		// the node's grid: origin = its lo corner, step 2^e with 255·2^e >= extent (e as a signed byte)
-		uint32_t eb[3];
-		double st[3];
-		for (int a = 0; a < 3; ++a) {
-			const double ext = (double)x.hi[a] - (double)x.lo[a];
-			int e = -126;
-			if (ext > 0.0) {
-				(void)std::frexp(ext / 255.0, &e); // ext/255 = m·2^e, m in [0.5, 1)
-				e = std::max(e - 1, -126);
-			}
-			while (e < 127 && std::ldexp(255.0, e) < ext) ++e;
-			eb[a] = (uint32_t)(e & 0xff);
-			st[a] = std::ldexp(1.0, e);
-		}
-		uint32_t w[6] = {0, 0, 0, 0, 0, 0}; // lo.x, hi.x, lo.y, hi.y, lo.z, hi.z: one byte per child
-		for (int k = 0; k < nk; ++k) {
-			const BuildNode &c = bvh.nodes[kid[k]];
-			for (int a = 0; a < 3; ++a) {
-				// origin + q·2^e is exact in double (q <= 255): the quantised box contains the fp32 box
-				double ql = std::floor(((double)c.lo[a] - (double)x.lo[a]) / st[a]);
-				double qh = std::ceil(((double)c.hi[a] - (double)x.lo[a]) / st[a]);
-				ql = std::min(255.0, std::max(0.0, ql));
-				qh = std::min(255.0, std::max(0.0, qh));
-				while (ql > 0.0 && (double)x.lo[a] + ql * st[a] > (double)c.lo[a]) ql -= 1.0;
-				while (qh < 255.0 && (double)x.lo[a] + qh * st[a] < (double)c.hi[a]) qh += 1.0;
-				w[2 * a] |= (uint32_t)ql << (8 * k);
-				w[2 * a + 1] |= (uint32_t)qh << (8 * k);
-			}
-		}
-		auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-		WideNode g;
-		g.w[0] = fbits(x.lo[0]); g.w[1] = fbits(x.lo[1]); g.w[2] = fbits(x.lo[2]);
-		g.w[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)ni << 24) | ((uint32_t)nk << 28);
-		for (int q = 0; q < 6; ++q) g.w[4 + q] = w[q];
-		g.w[10] = inner_base;
-		g.w[11] = ~((tri_base - (uint32_t)ni) << 3);
-		out.nodes[it.out_id] = g;
-		if (out.build_of.size() < out.nodes.size()) out.build_of.resize(out.nodes.size(), 0u);
-		out.build_of[it.out_id] = it.build_id;
-		if (kids_of.size() < out.nodes.size()) kids_of.resize(out.nodes.size(), 0u);
-		kids_of[it.out_id] = (uint32_t)nk | ((uint32_t)ni << 4);
+		plan[it.out_id] = p;
 	}
-	// stack bound: on the way down a node leaves at most n_children − 1 entries behind; children have larger indices
-	std::vector<uint32_t> need(out.nodes.size(), 0u);
-	for (size_t i = out.nodes.size(); i-- > 0;) {
-		const uint32_t nk = kids_of[i] & 15u, ni = kids_of[i] >> 4, base = out.nodes[i].w[10];
+	if (next_tri != bvh.order.size()) { err = "internal error: the 4-wide layout lost triangles"; return -1; }
+	// 2. the node words (parallel): the node's grid and the children's boxes on it
+	out.nodes.resize(plan.size());
+	out.build_of.resize(plan.size());
+	auto encode = [&](size_t lo_i, size_t hi_i) {
+		for (size_t i = lo_i; i < hi_i; ++i) {
+			const Plan &p = plan[i];
+			const BuildNode &x = bvh.nodes[p.build_id];
+			// origin = the node's lo corner, step 2^e with 255·2^e >= extent (e as a signed byte)
+			uint32_t eb[3];
+			double st[3];
+			for (int a = 0; a < 3; ++a) {
+				const double ext = (double)x.hi[a] - (double)x.lo[a];
+				int e = -126;
+				if (ext > 0.0) {
+					(void)std::frexp(ext / 255.0, &e); // ext/255 = m·2^e, m in [0.5, 1)
+					e = std::max(e - 1, -126);
+				}
+				while (e < 127 && std::ldexp(255.0, e) < ext) ++e;
+				eb[a] = (uint32_t)(e & 0xff);
+				st[a] = std::ldexp(1.0, e);
+			}
+			uint32_t w[6] = {0, 0, 0, 0, 0, 0}; // lo.x, hi.x, lo.y, hi.y, lo.z, hi.z: one byte per child
+			for (uint32_t k = 0; k < p.nk; ++k) {
+				const BuildNode &c = bvh.nodes[p.kid[k]];
+				for (int a = 0; a < 3; ++a) {
+					// origin + q·2^e is exact in double (q <= 255): the quantised box contains the fp32 box
+					double ql = std::floor(((double)c.lo[a] - (double)x.lo[a]) / st[a]);
+					double qh = std::ceil(((double)c.hi[a] - (double)x.lo[a]) / st[a]);
+					ql = std::min(255.0, std::max(0.0, ql));
+					qh = std::min(255.0, std::max(0.0, qh));
+					while (ql > 0.0 && (double)x.lo[a] + ql * st[a] > (double)c.lo[a]) ql -= 1.0;
+					while (qh < 255.0 && (double)x.lo[a] + qh * st[a] < (double)c.hi[a]) qh += 1.0;
+					w[2 * a] |= (uint32_t)ql << (8 * k);
+					w[2 * a + 1] |= (uint32_t)qh << (8 * k);
+				}
+			}
+			auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+			WideNode g;
+			g.w[0] = fbits(x.lo[0]); g.w[1] = fbits(x.lo[1]); g.w[2] = fbits(x.lo[2]);
+			g.w[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | (p.ni << 24) | (p.nk << 28);
+			for (int q = 0; q < 6; ++q) g.w[4 + q] = w[q];
+			g.w[10] = p.inner_base;
+			g.w[11] = ~((p.tri_base - p.ni) << 3);
+			out.nodes[i] = g;
+			out.build_of[i] = p.build_id;
+		}
+	};
+	const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::max(1u, n_threads), plan.size() / 4096 + 1));
+	if (nt == 1) {
+		encode(0, plan.size());
+	} else {
+		std::vector<std::future<void>> jobs;
+		const size_t step = (plan.size() + nt - 1) / nt;
+		for (unsigned t = 0; t < nt; ++t) {
+			const size_t a0 = std::min(plan.size(), (size_t)t * step), a1 = std::min(plan.size(), a0 + step);
+			if (a0 < a1) jobs.push_back(std::async(std::launch::async, encode, a0, a1));
+		}
+		for (auto &j : jobs) j.get();
+	}
+	// 3. stack bound: on the way down a node leaves at most n_children − 1 entries behind; children have larger indices
+	std::vector<uint32_t> need(plan.size(), 0u);
+	for (size_t i = plan.size(); i-- > 0;) {
 		uint32_t below = 0;
-		for (uint32_t k = 0; k < ni; ++k) below = std::max(below, need[base + k]);
-		need[i] = nk - 1u + below;
+		for (uint32_t k = 0; k < plan[i].ni; ++k) below = std::max(below, need[plan[i].inner_base + k]);
+		need[i] = plan[i].nk - 1u + below;
 	}
 	out.stack_need = need[0];
-	if (next_tri != bvh.order.size()) { err = "internal error: the 4-wide layout lost triangles"; return -1; }
 	return 0;
 }
 

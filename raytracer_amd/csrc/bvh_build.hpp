@@ -43,7 +43,7 @@ struct Wide4 {
 	uint32_t stack_need = 0;        // entries the deepest root-to-leaf path can leave on the traversal stack
 };
 // Collapses a binary hierarchy whose leaves hold ONE triangle each.  Returns 0, or -1 with a message.
-int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err);
+int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err, unsigned n_threads = 1);
 // Host-side check of every invariant the kernels rely on (tests): each child's box, decoded as the kernels decode it,
 // contains the child's fp32 box; references are in range; every triangle position is used exactly once; stack_need
 // bounds every path.  Returns the number of violations.

@@ -308,7 +308,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	Wide4 wide;
 	{
 		std::string err;
-		if (build_wide(bvh, wide, err)) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: " + err); return nullptr; }
+		if (build_wide(bvh, wide, err, threads)) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: " + err); return nullptr; }
 	}
 	static_assert(sizeof(WideNode) == sizeof(WNode), "host and device layout of the 4-wide node");
 	const std::vector<uint32_t> &leaf_pos = wide.leaf_pos;
@@ -623,7 +623,7 @@ int rtmi_debug_check_hierarchy(const double *tri_xyz, uint64_t n_tris, uint64_t 
 	Bvh2 bvh = build_bvh2(tri_xyz, n_tris, 1, kStackDepth - 2, threads);
 	Wide4 wide;
 	std::string err;
-	if (build_wide(bvh, wide, err)) return fail(std::string(who) + ": " + err);
+	if (build_wide(bvh, wide, err, threads)) return fail(std::string(who) + ": " + err);
 	stats[0] = check_wide(bvh, wide);
 	stats[1] = wide.nodes.size();
 	stats[2] = wide.stack_need;
