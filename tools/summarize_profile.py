@@ -65,8 +65,13 @@ for k in KERNELS:
         lines.append("HBM-side bytes per dispatch: FETCH_SIZE %.4g B raw (x2 = %.4g B, gfx950 wide-read correction), WRITE_SIZE %.4g B." % (rd, 2 * rd, wr))
         traffic[k] = {"fetch_raw": rd, "write": wr, "hbm_bytes": 2 * rd + wr}
     if "TCC_HIT_sum" in avg:
+        traffic.setdefault(k, {})["l2_hit_rate"] = avg["TCC_HIT_sum"] / (avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])
         lines.append("L2 hit rate = TCC_HIT/(TCC_HIT+TCC_MISS) = %.3f." % (avg["TCC_HIT_sum"] / (avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])))
     if "SQ_WAVE_CYCLES" in avg and "SQ_ACTIVE_INST_VALU" in avg:
+        traffic.setdefault(k, {})["valu_active_share_of_wave_cycles"] = avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_WAVE_CYCLES"]
+        traffic[k]["wait_any_share_of_wave_cycles"] = avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"]
+        if "SQ_THREAD_CYCLES_VALU" in avg:
+            traffic[k]["lanes_active_per_valu_instruction"] = avg["SQ_THREAD_CYCLES_VALU"] / avg["SQ_ACTIVE_INST_VALU"]
         lines.append("Wave-cycle shares: WAIT_ANY %.2f, WAIT_INST_ANY %.2f, ACTIVE_INST_ANY %.2f; VALU-active share of wave cycles %.2f; VALU insts per wave %.0f." % (
             avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"], avg["SQ_WAIT_INST_ANY"] / avg["SQ_WAVE_CYCLES"], avg["SQ_ACTIVE_INST_ANY"] / avg["SQ_WAVE_CYCLES"],
             avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_WAVE_CYCLES"], avg["SQ_INSTS_VALU"] / avg["SQ_WAVES"]))
@@ -78,10 +83,13 @@ open(os.path.join(root, "profiles", tag + "_rocprof.md"), "w").write("\n".join(l
 # traffic.json: what bench.py reports as roofline.traffic (keyed by the launch it was measured on)
 n = 65536
 out = {}
-if "k_jacobi_sweep" in traffic:
+if "k_jacobi_sweep" in traffic and "hbm_bytes" in traffic["k_jacobi_sweep"]:
     out["k_jacobi_sweep"] = {"bytes_per_launch": 4.0 * n * n, "hbm_bytes": traffic["k_jacobi_sweep"]["hbm_bytes"], "source": tag}
-if "k_primary_closest" in traffic:
-    out["k_primary_closest"] = {"rays_per_launch": 3840 * 2160, "hbm_bytes": traffic["k_primary_closest"]["hbm_bytes"],
-                                "hbm_bytes_uncorrected": traffic["k_primary_closest"]["fetch_raw"] + traffic["k_primary_closest"]["write"], "source": tag}
+if "k_primary_closest" in traffic and "hbm_bytes" in traffic["k_primary_closest"]:
+    t = traffic["k_primary_closest"]
+    out["k_primary_closest"] = {"rays_per_launch": 3840 * 2160, "hbm_bytes": t["hbm_bytes"], "hbm_bytes_uncorrected": t["fetch_raw"] + t["write"], "source": tag}
+    for key in ("l2_hit_rate", "valu_active_share_of_wave_cycles", "wait_any_share_of_wave_cycles", "lanes_active_per_valu_instruction"):
+        if key in t:
+            out["k_primary_closest"][key] = round(t[key], 4)
 json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 print("\n".join(lines))
