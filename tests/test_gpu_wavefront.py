@@ -173,3 +173,41 @@ def test_soft_shadow_wavefront_studio(rt, oracle):
     sh = shits.cpu().numpy().view(rt.HIT_DTYPE).reshape(n, NP)
     want = (sh["tri"] != rt.MISS) & (sh["object"] != h["object"][:, None]) & ~miss[:, None]
     assert np.array_equal(contrib.cpu().numpy().reshape(n, NP), want.astype(np.uint8))
+
+
+def test_fused_secondary_ray_entries_argument_errors_and_empty_scene(rt):
+    """rtmi_ao_occlusion_dev / rtmi_soft_shadow_dev: NULL buffers, a non-positive radius and zero points are refused with
+    a message; zero rays is a no-op; an empty scene answers 'nothing hit' for every slot."""
+    import torch
+    st = torch.cuda.current_stream().cuda_stream
+    scene = rt.Scene(np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0.0]]))
+    n, spp = 4, 3
+    rays = torch.zeros(n * 64, dtype=torch.uint8, device="cuda"); hits = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+    nrm = torch.zeros(3, dtype=torch.float64, device="cuda"); occ = torch.zeros(n * spp, dtype=torch.uint8, device="cuda")
+    fac = torch.zeros(n, dtype=torch.float64, device="cuda")
+    with pytest.raises(rt.RtmiError, match="radius"):
+        scene.ao_occlusion_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, spp, 0.0, 1, occ.data_ptr(), st)
+    with pytest.raises(rt.RtmiError, match="NULL"):
+        scene.ao_occlusion_dev(nrm.data_ptr(), rays.data_ptr(), 0, n, spp, 2.0, 1, occ.data_ptr(), st)
+    with pytest.raises(rt.RtmiError, match="NULL|n_points"):
+        scene.soft_shadow_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, [0, 0, 1], 0, occ.data_ptr(), fac.data_ptr(), st)
+    scene.ao_occlusion_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), 0, spp, 2.0, 1, occ.data_ptr(), st)   # n == 0
+    # hit records that are all misses (tri = MISS): every slot 0, factor 1
+    h = np.zeros(n, rt.HIT_DTYPE); h["tri"] = rt.MISS; h["object"] = rt.MISS
+    hits.copy_(torch.from_numpy(h.view(np.uint8).copy()))
+    occ.fill_(5); fac.fill_(-1.0)
+    scene.ao_occlusion_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, spp, 2.0, 1, occ.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert int(occ.sum()) == 0
+    occ.fill_(5)
+    scene.soft_shadow_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, [0, 0, 1], spp, occ.data_ptr(), fac.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert int(occ.sum()) == 0 and bool((fac == 1.0).all())
+    empty = rt.Scene(np.zeros((0, 9)))
+    occ.fill_(5); fac.fill_(-1.0)
+    empty.ao_occlusion_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, spp, 2.0, 1, occ.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert int(occ.sum()) == 0
+    empty.soft_shadow_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, [0, 0, 1], spp, occ.data_ptr(), fac.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert bool((fac == 1.0).all())
