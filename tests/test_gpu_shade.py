@@ -91,6 +91,15 @@ def test_generation_beyond_depth_and_small_workspace(rt, oracle, monkeypatch):
     scene2, sh2 = _shader(rt, g, max_tree_depth=2, ao_rays=0)
     small, _ = sh2.Rasterize(cam)
     assert np.array_equal(full, small)
+    # the same with ambient occlusion on (AO frames and occlusion bytes are carved from the workspace per chunk; the
+    # sample streams are keyed by the ray, not by the slot, so chunks must not change a pixel)
+    monkeypatch.delenv("RTMI_SHADE_WS_MB")
+    scene3, sh3 = _shader(rt, g, "mats_amb", max_tree_depth=3, ao_rays=10, seed=5)
+    full_ao, _ = sh3.Rasterize(cam)
+    monkeypatch.setenv("RTMI_SHADE_WS_MB", "1")
+    scene4, sh4 = _shader(rt, g, "mats_amb", max_tree_depth=3, ao_rays=10, seed=5)
+    small_ao, _ = sh4.Rasterize(cam)
+    assert np.array_equal(full_ao, small_ao) and not np.array_equal(full_ao, full)
 
 
 def test_test1_frame_as_shipped(rt, oracle):
