@@ -111,10 +111,17 @@ def main():
     rays_rank = sum(multi.pixels_of_rank(x_res, y_res, TILE[0], TILE[1], (rank + s) % world, world) for s in range(spp))
     rays_total = spp * n_pix
 
+    # At N > 1 a rank traces N launches of 1/N of the tiles per step.  A launch of a million rays leaves every resident wave
+    # with one chunk of the queue and ends in a long tail (tools/quick_tiles.py: 8 such launches on one stream take 2.2x the
+    # time of one full-frame launch, on 4 streams 1.05x), so the independent launches of a step go round-robin over up to
+    # 4 HIP streams (the box's hardware-queue limit) and the tail of one overlaps the start of the next.
+    lanes = [torch.cuda.Stream() for _ in range(min(4, spp))] if spp > 1 else []
+    lane_handles = [st.cuda_stream for st in lanes] or [stream]
+
     def step():
         for s in range(spp):
             scene.primary_dev(cam, frames[s].data_ptr(), sx=offs[s][0], sy=offs[s][1], tile=TILE,
-                              tile_first=(rank + s) % world, tile_stride=world, stream=stream)
+                              tile_first=(rank + s) % world, tile_stride=world, stream=lane_handles[s % len(lane_handles)])
 
     for _ in range(args.warmup):
         step()
@@ -127,7 +134,10 @@ def main():
         ev[k][1].record()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * spp)      # average duration of one launch
+    if spp == 1:
+        kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps          # average duration of one launch (HIP events)
+    else:
+        kernel_ms = dt * 1e3 / (args.steps * spp)                               # launches overlap across streams: wall time per launch
     mrays = rays_total * args.steps / dt / 1e6
 
     # traversal work of the frame (diagnostic kernel, untimed) -> roofline of the closest-hit kernel
