@@ -148,6 +148,11 @@ int rtmi_shadow_rays_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *
 int rtmi_ao_rays_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
                      uint32_t spp, double radius, uint64_t seed, rtmi_ray *d_out, void *stream);
 int rtmi_occlusion_fraction_dev(const uint8_t *d_occluded, uint64_t n, uint32_t spp, double *d_out, void *stream);
+/*   rtmi_shadow_occlusion_dev  rtmi_shadow_rays_dev + rtmi_any_hit_dev in one launch (Shader::generateNormalShadows,
+ *                          Render2/shader.cpp:105-138): the shadow ray of each hit is built inside the any-hit kernel;
+ *                          d_occluded[k] as the two calls would write it.  Misses give 0. */
+int rtmi_shadow_occlusion_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                              const double light_center[3], uint8_t *d_occluded, void *stream);
 /*   rtmi_ao_occlusion_dev  the whole loop of Shader::findOcclusionNew (Render2/shader.cpp:172-229) in one launch:
  *                          d_occluded[k·spp + s] is byte for byte what rtmi_ao_rays_dev followed by rtmi_any_hit_dev
  *                          writes, but the spp rays per hit are built inside the any-hit kernel and never stored

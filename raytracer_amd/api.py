@@ -75,7 +75,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_
 SYMBOLS = [
     "rtmi_last_error", "rtmi_device_count", "rtmi_triangle_intersection", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_get_info",
     "rtmi_closest_hit", "rtmi_closest_hit_dev", "rtmi_camera_setup", "rtmi_primary_closest_hit_dev",
-    "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev", "rtmi_debug_check_hierarchy",
+    "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev", "rtmi_shadow_occlusion_dev", "rtmi_debug_check_hierarchy",
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev",
     "rtmi_shader_create", "rtmi_shader_destroy", "rtmi_trace_dev", "rtmi_render_frame_dev", "rtmi_tone_map_dev",
@@ -115,6 +115,7 @@ def _load():
     L.rtmi_shadow_rays_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
     L.rtmi_ao_rays_dev.argtypes = [vp, vp, vp, vp, u64, u32, dbl, u64, vp, vp]
     L.rtmi_ao_occlusion_dev.argtypes = [vp, vp, vp, vp, u64, u32, dbl, u64, vp, vp]
+    L.rtmi_shadow_occlusion_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
     L.rtmi_debug_check_hierarchy.argtypes = [vp, u64, vp]
     L.rtmi_occlusion_fraction_dev.argtypes = [vp, u64, u32, vp, vp]
     L.rtmi_soft_shadow_rays_dev.argtypes = [vp, vp, vp, vp, u64, vp, u32, vp, vp]
@@ -334,6 +335,11 @@ class Scene:
         """Shader::generateSoftShadows for a batch of hit records in one launch (+ reduction): the factor per hit."""
         lc = _np(light_center, np.float64, (3,))
         _check(lib.rtmi_soft_shadow_dev(self.handle, d_normals, d_rays, d_hits, n, _ptr(lc), n_points, d_contrib, d_factor, stream))
+
+    def shadow_occlusion_dev(self, d_normals, d_rays, d_hits, n, light_center, d_occluded, stream=0):
+        """Shader::generateNormalShadows for a batch of hit records in one launch: shadow_rays_dev + occluded_dev."""
+        lc = _np(light_center, np.float64, (3,))
+        _check(lib.rtmi_shadow_occlusion_dev(self.handle, d_normals, d_rays, d_hits, n, _ptr(lc), d_occluded, stream))
 
     def ao_occlusion_dev(self, d_normals, d_rays, d_hits, n, spp, radius, seed, d_occluded, stream=0):
         """The loop of Shader::findOcclusionNew in one launch: ao_rays_dev + occluded_dev without the rays in memory."""

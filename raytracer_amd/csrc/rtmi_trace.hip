@@ -99,6 +99,36 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_AO_WAVES) void k_ao_occlusion(SceneDev S, const dou
 	trace_queue<true, false, false>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
 }
 
+// Shader::generateNormalShadows (shader.cpp:105-138) in one launch: the shadow ray of hit k (origin P + 0.01·normal, direction
+// Unit(C − P), :116-127) is built in the refill of the any-hit queue; occluded[k] = Cast's verdict (:131).  The operations are
+// those of k_shadow_rays (rtmi_wavefront.hip).
+RTMI_TRAVERSAL_KERNEL_W(RTMI_AO_WAVES) void k_shadow_occlusion(SceneDev S, const double *__restrict__ v1_orig, const double *__restrict__ normals,
+                                                 const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits, uint32_t n_items,
+                                                 double cx, double cy, double cz, int *__restrict__ counter, Tune tune,
+                                                 uint8_t *__restrict__ occluded) {
+	extern __shared__ int stack[];
+	auto fetch = [&](uint32_t k, RayD &R) {
+		const rtmi_hit h = hits[k];
+		if (h.tri == RTMI_MISS) {
+			occluded[k] = 0;
+			return false;
+		}
+		const D3 nrm = d3(normals[3 * (size_t)h.tri], normals[3 * (size_t)h.tri + 1], normals[3 * (size_t)h.tri + 2]);
+		const D3 P = hit_point(rays[k], v1_orig + 3 * (size_t)h.tri, nrm);
+		const D3 dir = unit(d3(cx, cy, cz) - P);
+		const D3 org = P + (0.01 * nrm);
+		R.ox = org.x; R.oy = org.y; R.oz = org.z;
+		R.dx = dir.x; R.dy = dir.y; R.dz = dir.z;
+		R.tmax = RTMI_INFINITY;
+		return true;
+	};
+	auto emit = [&](uint32_t k, const HitQ &h, RayD &) {
+		occluded[k] = h.pos != RTMI_MISS ? 1 : 0;
+		return false;
+	};
+	trace_queue<true, false, false>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
+}
+
 // Shader::generateSoftShadows (shader.cpp:41-103) in one launch, like k_ao_occlusion: the ray of item k·n_points + i·divY + j
 // toward grid point (i, j) through the light centre (:60-71, :90-91) is built in the refill of a closest-hit queue, and
 // only its verdict is stored: 1 iff it hits a triangle of ANOTHER object than the shaded hit's (:93-100).  The operations
@@ -520,6 +550,26 @@ static int ao_occlusion_dev(rtmi_scene *s, const double *d_normals, const rtmi_r
 	return launch_check(who);
 }
 
+static int shadow_occlusion_dev(rtmi_scene *s, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                                const double light_center[3], uint8_t *d_occ, void *stream) {
+	const char *who = "rtmi_shadow_occlusion_dev";
+	if (check_scene(s, who)) return -1;
+	if (n == 0) return 0;
+	if (!d_normals || !d_rays || !d_hits || !light_center || !d_occ) return fail(std::string(who) + ": NULL argument");
+	if (n > 0xff000000ull) return fail(std::string(who) + ": too many rays for one launch");
+	if (s->n_tris == 0) {
+		if (hipMemsetAsync(d_occ, 0, n, (hipStream_t)stream) != hipSuccess) return fail(std::string(who) + ": hipMemsetAsync failed");
+		return 0;
+	}
+	int *slot = queue_slot(s, (hipStream_t)stream, who);
+	if (!slot) return -1;
+	Tune tune = refill_threshold();
+	tune.thresh = (int)std::min(64u, env_uint("RTMI_REFILL_ANY", 32));
+	hipLaunchKernelGGL(k_shadow_occlusion, dim3(persistent_grid(s, k_shadow_occlusion, n)), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev,
+	                   s->d_v1_orig, d_normals, d_rays, d_hits, (uint32_t)n, light_center[0], light_center[1], light_center[2], slot, tune, d_occ);
+	return launch_check(who);
+}
+
 static int soft_shadow_dev(rtmi_scene *s, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
                            const double light_center[3], uint32_t n_points, uint8_t *d_contrib, double *d_factor, void *stream) {
 	const char *who = "rtmi_soft_shadow_dev";
@@ -610,6 +660,11 @@ int rtmi_closest_hit_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, rtmi
 int rtmi_any_hit(rtmi_scene *s, const rtmi_ray *rays, uint64_t n, uint8_t *occluded) {
 	return trace_host<true>(s, rays, n, nullptr, occluded, "rtmi_any_hit");
 }
+int rtmi_shadow_occlusion_dev(rtmi_scene *s, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
+                              const double light_center[3], uint8_t *d_occluded, void *stream) {
+	return shadow_occlusion_dev(s, d_normals, d_rays, d_hits, n, light_center, d_occluded, stream);
+}
+
 int rtmi_soft_shadow_dev(rtmi_scene *s, const double *d_normals, const rtmi_ray *d_rays, const rtmi_hit *d_hits, uint64_t n,
                          const double light_center[3], uint32_t n_points, uint8_t *d_contrib, double *d_factor, void *stream) {
 	return soft_shadow_dev(s, d_normals, d_rays, d_hits, n, light_center, n_points, d_contrib, d_factor, stream);

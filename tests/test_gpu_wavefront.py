@@ -60,6 +60,11 @@ def test_shadow_wavefront_test1(rt, oracle):
     o = occ.cpu().numpy()
     assert np.array_equal(o[k], g["shadow_occluded"])
     assert np.all(o[~hit] == 0)
+    # the fused launch (shadow rays built inside the any-hit kernel) writes the same bytes
+    occ2 = torch.full((f.n,), 7, dtype=torch.uint8, device="cuda")
+    f.scene.shadow_occlusion_dev(f.normals.data_ptr(), f.rays.data_ptr(), f.hits.data_ptr(), f.n, g["light_center"], occ2.data_ptr(), f.st)
+    torch.cuda.synchronize()
+    assert torch.equal(occ, occ2)
     assert np.array_equal(o[hit], oracle.any_hit(g["tris"], so, sd))
 
 

@@ -52,6 +52,13 @@ e1.record(); torch.cuda.synchronize()
 tf = e0.elapsed_time(e1)
 print("   fused AO (rtmi_ao_occlusion_dev): %.2f ms against %.2f ms for generate + any-hit (%.0f Mrays/s); same bytes: %s; frame %.2f ms" % (
     tf, t[1] + t[2], n * spp / tf / 1e3, bool(torch.equal(occ, occ2)), sum(t) - t[1] - t[2] + tf), flush=True)
+socc2 = torch.zeros_like(socc)
+def sh2(): scene.shadow_rays_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, light, sh.data_ptr(), st); scene.occluded_dev(sh.data_ptr(), n, socc.data_ptr(), st)
+def sh1(): scene.shadow_occlusion_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, light, socc2.data_ptr(), st)
+for f in (sh2, sh1):
+    f(); torch.cuda.synchronize(); e0.record(); f(); e1.record(); torch.cuda.synchronize()
+    print("   hard shadows, %d rays, %s: %.3f ms" % (n, "generate + any-hit" if f is sh2 else "fused (rtmi_shadow_occlusion_dev)", e0.elapsed_time(e1)), flush=True)
+print("   same bytes: %s" % bool(torch.equal(socc, socc2)), flush=True)
 # soft shadows (BASELINE config 4 names them; the shipped Shade has the call commented out): 100 rays per hit, 3 steps vs fused
 NP = 100
 m = n // 4                                         # a quarter of the frame: the 3-step path needs 88 B per ray
