@@ -8,7 +8,7 @@
 //
 // The reference recurses per pixel; here one generation of the ray tree is one batch:
 //   closest hit -> k_shade_pre (hit point, shadow ray, refraction children) -> any hit (shadow) -> k_ao_list
-//   -> k_node_ao_rays -> any hit (AO) -> k_shade_post (colour, reflection child) -> next generation ... -> k_fold
+//   (+ AO frames) -> k_ao_trace (AO rays built in the any-hit kernel) -> k_shade_post (colour, reflection child) -> next generation ... -> k_fold
 // Generations are COMPACT: a node reserves slots for its children from a device-side counter (one atomic per wave),
 // AO rays exist only for the nodes that will use the answer, and every launch reads its item count on the device, so a
 // frame is queued without the host ever waiting.  Work the reference does but whose result it never uses is skipped:
@@ -273,52 +273,45 @@ __global__ void __launch_bounds__(kReserveBlock) __attribute__((amdgpu_waves_per
 }
 
 // The AO list: nodes whose AO answer will be used (k_shade_pre's flag, and not shadowed).  ao_at[k] = position or kNone.
-__global__ void __launch_bounds__(kReserveBlock) k_ao_list(const uint32_t *__restrict__ d_count, const uint8_t *__restrict__ wants_ao,
-                                                          const uint8_t *__restrict__ shadowed, uint32_t *__restrict__ ao_at,
-                                                          uint32_t *__restrict__ ao_count, uint32_t *__restrict__ ao_slot) {
-	const uint64_t count = *d_count;
-	RTMI_FOR_ITEMS(k, in, count) {
-		const uint32_t need = (in && wants_ao[k] && !shadowed[k]) ? 1u : 0u;
-		const uint32_t at = reserve(ao_count, need);
-		if (in) ao_at[k] = need ? at : kNone;
-		if (need) ao_slot[at] = (uint32_t)k;
-	}
-}
-
-// findOcclusionNew (shader.cpp:140-232) for the listed nodes, in two launches and without the rays in memory:
-// k_node_ao_frames — one thread per node: hit point, hemisphere frame (:153-171) and the node's sample stream
-//                    (mix64(seed ^ path), root ray index), 112 B per node;
-// k_ao_trace       — any-hit queue over (node, sample) items; a lane builds its ray from the node's frame and the square
-//                    point of (stream, sample) when it refills (:177-220), traces it with tmax = R (:226) and writes
-//                    the byte at[·spp + s].  Whole waves refill: building a ray costs more than reading one.
+// A listed node gets its AO frame at that position right away: hit point, hemisphere frame (shader.cpp:153-171) and the
+// node's sample stream (mix64(seed ^ path), root ray index), 112 B.
 struct __attribute__((aligned(16))) AoFrame {
 	double P[3], X[3], Y[3], Z[3];
 	uint64_t stream, pad;
 };
 
-__global__ void __launch_bounds__(256) k_node_ao_frames(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
-                                                        const Node *__restrict__ nodes, const uint32_t *__restrict__ ao_slot,
-                                                        const uint32_t *__restrict__ ao_count, const uint64_t *__restrict__ root,
-                                                        uint64_t seed, AoFrame *__restrict__ out) {
-	const uint64_t count = *ao_count;
-	RTMI_FOR_ITEMS(at, in, count) {
-		if (!in) continue;
-		const uint32_t k = ao_slot[at];
-		const rtmi_hit h = hits[k];
-		const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
-		const D3 P = hit_point(rays[k], S.v1_orig + 3 * (size_t)h.tri, Ns);
-		D3 X, Y, Z;
-		ao_frame(Ns, X, Y, Z);
-		AoFrame f;
-		f.P[0] = P.x; f.P[1] = P.y; f.P[2] = P.z;
-		f.X[0] = X.x; f.X[1] = X.y; f.X[2] = X.z;
-		f.Y[0] = Y.x; f.Y[1] = Y.y; f.Y[2] = Y.z;
-		f.Z[0] = Z.x; f.Z[1] = Z.y; f.Z[2] = Z.z;
-		f.stream = wf_mix64(wf_mix64(seed ^ (uint64_t)nodes[k].path) ^ root[nodes[k].rootslot]);
-		f.pad = 0;
-		out[at] = f;
+__global__ void __launch_bounds__(kReserveBlock) k_ao_list(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
+                                                          const Node *__restrict__ nodes, const uint64_t *__restrict__ root, uint64_t seed,
+                                                          const uint32_t *__restrict__ d_count, const uint8_t *__restrict__ wants_ao,
+                                                          const uint8_t *__restrict__ shadowed, uint32_t *__restrict__ ao_at,
+                                                          uint32_t *__restrict__ ao_count, AoFrame *__restrict__ frames) {
+	const uint64_t count = *d_count;
+	RTMI_FOR_ITEMS(k, in, count) {
+		const uint32_t need = (in && wants_ao[k] && !shadowed[k]) ? 1u : 0u;
+		const uint32_t at = reserve(ao_count, need);
+		if (in) ao_at[k] = need ? at : kNone;
+		if (need) {
+			const rtmi_hit h = hits[k];
+			const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
+			const D3 P = hit_point(rays[k], S.v1_orig + 3 * (size_t)h.tri, Ns);
+			D3 X, Y, Z;
+			ao_frame(Ns, X, Y, Z);
+			AoFrame f;
+			f.P[0] = P.x; f.P[1] = P.y; f.P[2] = P.z;
+			f.X[0] = X.x; f.X[1] = X.y; f.X[2] = X.z;
+			f.Y[0] = Y.x; f.Y[1] = Y.y; f.Y[2] = Y.z;
+			f.Z[0] = Z.x; f.Z[1] = Z.y; f.Z[2] = Z.z;
+			f.stream = wf_mix64(wf_mix64(seed ^ (uint64_t)nodes[k].path) ^ root[nodes[k].rootslot]);
+			f.pad = 0;
+			frames[at] = f;
+		}
 	}
 }
+
+// findOcclusionNew (shader.cpp:140-232) for the listed nodes, without the rays in memory:
+// k_ao_trace       — any-hit queue over (node, sample) items; a lane builds its ray from the node's frame and the square
+//                    point of (stream, sample) when it refills (:177-220), traces it with tmax = R (:226) and writes
+//                    the byte at[·spp + s].  Whole waves refill: building a ray costs more than reading one.
 
 RTMI_TRAVERSAL_KERNEL_W(4) void k_ao_trace(SceneDev scene, const AoFrame *__restrict__ frames, const uint32_t *__restrict__ ao_count,
                                            uint64_t cap_items, uint32_t spp, double R, int *__restrict__ counter, Tune tune,
@@ -503,7 +496,7 @@ struct Chunk {
 	rtmi_ray *shadow;
 	AoFrame *ao;
 	uint8_t *shadowed, *ao_occ, *wants_ao;
-	uint32_t *ao_slot, *ao_at;
+	uint32_t *ao_at;
 	uint64_t *root;
 	uint32_t *counts; // [0, levels]: nodes per generation (one spare), [levels+1, 2·levels]: AO-list length per generation
 };
@@ -541,7 +534,7 @@ static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t 
 	const uint64_t mx = c.slots[levels - 1];
 	const size_t o_hits = take(mx * sizeof(rtmi_hit)), o_sh = take(mx * sizeof(rtmi_ray)), o_shb = take(mx);
 	const size_t o_ao = take(c.spp ? mx * sizeof(AoFrame) : 0), o_aob = take(c.spp ? mx * c.spp : 0);
-	const size_t o_aos = take(c.spp ? mx * sizeof(uint32_t) : 0), o_aoat = take(c.spp ? mx * sizeof(uint32_t) : 0), o_want = take(mx);
+	const size_t o_aoat = take(c.spp ? mx * sizeof(uint32_t) : 0), o_want = take(mx);
 	const size_t o_root = take(cap * sizeof(uint64_t));
 	const size_t o_counts = take((2 * levels + 2) * sizeof(uint32_t));
 	if (off > sh->ws_bytes) {
@@ -556,7 +549,6 @@ static int plan_chunk(rtmi_shader *sh, uint64_t want, uint32_t levels, uint32_t 
 	c.shadowed = (uint8_t *)(sh->ws + o_shb);
 	c.ao = (AoFrame *)(sh->ws + o_ao);
 	c.ao_occ = (uint8_t *)(sh->ws + o_aob);
-	c.ao_slot = (uint32_t *)(sh->ws + o_aos);
 	c.ao_at = (uint32_t *)(sh->ws + o_aoat);
 	c.wants_ao = (uint8_t *)(sh->ws + o_want);
 	c.root = (uint64_t *)(sh->ws + o_root);
@@ -580,10 +572,8 @@ static int run_chunk(rtmi_shader *sh, const Chunk &c, uint64_t n, const rtmi_tra
 		                   c.nodes[g], c.shadow, c.wants_ao, kid_cnt, kid_rays, kid_nodes);
 		if (any_hit_counted(sh->scene, c.shadow, cap, cnt, 1, c.shadowed, st, who)) return -1;
 		if (c.spp) {
-			hipLaunchKernelGGL(k_ao_list, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, cnt, c.wants_ao, c.shadowed, c.ao_at, ao_cnt,
-			                   c.ao_slot);
-			hipLaunchKernelGGL(k_node_ao_frames, grid_for(sh, cap), dim3(256), 0, st, S, c.rays[g], c.hits, c.nodes[g], c.ao_slot, ao_cnt,
-			                   c.root, p.seed, c.ao);
+			hipLaunchKernelGGL(k_ao_list, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, S, c.rays[g], c.hits, c.nodes[g], c.root, p.seed, cnt,
+			                   c.wants_ao, c.shadowed, c.ao_at, ao_cnt, c.ao);
 			int *slot = queue_slot(sh->scene, st, who);
 			if (!slot) return -1;
 			Tune tune = refill_threshold();
