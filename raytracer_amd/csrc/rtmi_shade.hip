@@ -244,7 +244,8 @@ __global__ void __launch_bounds__(kReserveBlock) __attribute__((amdgpu_waves_per
 							}
 						}
 					} else {
-						ndkind = kOpaque; // colour and reflection: k_shade_post
+						ndkind = kOpaque; // colour and reflection: k_shade_post.  Until then the colour slot carries the hit point
+						ndc = P;          // for k_ao_list and k_shade_post (the same doubles they would recompute)
 						ao = nonzero(m.ambient) ? 1 : 0;
 						has_shadow = true;
 						sh_o = P + (0.01 * Ns); sh_d = unit(ld(S.lights[0].center) - P); // :122,127
@@ -280,7 +281,7 @@ struct __attribute__((aligned(16))) AoFrame {
 	uint64_t stream, pad;
 };
 
-__global__ void __launch_bounds__(kReserveBlock) k_ao_list(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
+__global__ void __launch_bounds__(kReserveBlock) k_ao_list(ShadeDev S, const rtmi_hit *__restrict__ hits,
                                                           const Node *__restrict__ nodes, const uint64_t *__restrict__ root, uint64_t seed,
                                                           const uint32_t *__restrict__ d_count, const uint8_t *__restrict__ wants_ao,
                                                           const uint8_t *__restrict__ shadowed, uint32_t *__restrict__ ao_at,
@@ -291,9 +292,8 @@ __global__ void __launch_bounds__(kReserveBlock) k_ao_list(ShadeDev S, const rtm
 		const uint32_t at = reserve(ao_count, need);
 		if (in) ao_at[k] = need ? at : kNone;
 		if (need) {
-			const rtmi_hit h = hits[k];
-			const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
-			const D3 P = hit_point(rays[k], S.v1_orig + 3 * (size_t)h.tri, Ns);
+			const D3 Ns = ld(S.normals + 3 * (size_t)hits[k].tri);
+			const D3 P = ld(nodes[k].c); // the hit point (object.cpp:23), left there by k_shade_pre
 			D3 X, Y, Z;
 			ao_frame(Ns, X, Y, Z);
 			AoFrame f;
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(kReserveBlock) __attribute__((amdgpu_waves_per
 			const rtmi_material &m = S.mats[h.object];
 			const D3 diffuse = ld(m.diffuse), specular = ld(m.specular), ambient = ld(m.ambient), reflective = ld(m.reflectivity);
 			const D3 Ns = ld(S.normals + 3 * (size_t)h.tri);
-			const D3 P = hit_point(r, S.v1_orig + 3 * (size_t)h.tri, Ns);
+			const D3 P = ld(nodes[k].c);    // the hit point, left in the colour slot by k_shade_pre
 			const D3 N = unit(Ns);          // :416
 			const D3 E = unit(ld(r.o) - P); // :417
 			D3 color = d3(0, 0, 0);
@@ -572,7 +572,7 @@ static int run_chunk(rtmi_shader *sh, const Chunk &c, uint64_t n, const rtmi_tra
 		                   c.nodes[g], c.shadow, c.wants_ao, kid_cnt, kid_rays, kid_nodes);
 		if (any_hit_counted(sh->scene, c.shadow, cap, cnt, 1, c.shadowed, st, who)) return -1;
 		if (c.spp) {
-			hipLaunchKernelGGL(k_ao_list, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, S, c.rays[g], c.hits, c.nodes[g], c.root, p.seed, cnt,
+			hipLaunchKernelGGL(k_ao_list, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, S, c.hits, c.nodes[g], c.root, p.seed, cnt,
 			                   c.wants_ao, c.shadowed, c.ao_at, ao_cnt, c.ao);
 			int *slot = queue_slot(sh->scene, st, who);
 			if (!slot) return -1;
