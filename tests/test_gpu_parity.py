@@ -259,6 +259,36 @@ def test_wide_node_layouts_vs_brute_force(rt, oracle, case):
         assert (tri >= 0).sum() > 20
 
 
+def test_wide_nodes_fuzz_many_small_scenes(rt, oracle):
+    """150 random scenes of 1..60 triangles (every shape of a small 4-wide hierarchy: leaf roots, nodes of 2, 3 and 4
+    children, leaves beside inner children), edge lengths over five decades, 400 rays each: closest and any hit bit for bit
+    against the brute-force oracle."""
+    rng = np.random.default_rng(2024)
+    total_hits = 0
+    for it in range(150):
+        n = int(rng.integers(1, 61))
+        edge = 10.0 ** rng.uniform(-3, 1.5)
+        c = rng.uniform(-1.0, 1.0, (n, 3)) * 10.0 ** rng.uniform(-1, 2)
+        tris = np.concatenate([c, c + rng.uniform(-edge, edge, (n, 3)), c + rng.uniform(-edge, edge, (n, 3))], axis=1)
+        m = 400
+        o = rng.uniform(-1.5, 1.5, (m, 3)) * (np.abs(tris).max() + 1.0)
+        aim = tris[rng.integers(0, n, m)].reshape(m, 3, 3)
+        w = rng.dirichlet([1.0, 1.0, 1.0], m)
+        d = (aim * w[:, :, None]).sum(1) - o                                  # aimed at a point of some triangle ...
+        d[m // 2:] += rng.normal(size=(m - m // 2, 3)) * edge                 # ... half of them only roughly
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        tmax = np.where(rng.random(m) < 0.7, 1e20, rng.uniform(0.1, 3.0, m) * np.linalg.norm(o, axis=1))
+        scene = rt.Scene(tris)
+        got = scene.Cast(rt.make_rays(o, d, tmax))
+        tri, t, u, v = oracle.closest_hit(tris, o, d, tmax)
+        assert np.array_equal(got["tri"], ids(tri)), (it, n)
+        assert np.array_equal(got["t"], t), (it, n)
+        assert np.array_equal(scene.Occluded(rt.make_rays(o, d, tmax)), oracle.any_hit(tris, o, d, tmax)), (it, n)
+        scene.close()
+        total_hits += int((tri >= 0).sum())
+    assert total_hits > 150 * 400 // 5
+
+
 def test_ties_on_shared_edges_and_duplicates(rt, oracle):
     """Rays aimed exactly at shared vertices / edges of a grid and at duplicated triangles: equal t ->
     smallest original id, as the reference's in-order scan (object.cpp:143-168)."""
