@@ -190,3 +190,50 @@ def test_frame_path_full_size_properties(rt, oracle, monkeypatch):
     ob = hits.cpu().numpy().view(rt.HIT_DTYPE)["object"].reshape(1080, 1920)
     lin = (ob != rt.MISS) & (ob != 3)          # object 3 = the microfacet box
     assert lin.sum() > 1000000 and np.abs((f0 + f1) - f01)[lin].max() < 1e-12
+
+
+def test_c4_room_fused_secondary_rays_equal_the_stored_ray_paths(rt):
+    """C4 at full size (99 804-triangle room, 1920x1080, 16 AO rays per pixel = 33 M rays; hard shadows; soft shadows on a
+    strip of the frame): the launches that build their rays inside the query kernel write exactly what the
+    generate -> store -> query paths write, and the occlusion statistics are those of a closed room."""
+    import torch
+    from raytracer_amd import workloads
+    room, normals, light = workloads.closed_box(91)
+    scene = rt.Scene(room)
+    cam = rt.Camera.from_cam14(np.array([1.0, 1.0, 5.0, 6.0, 6.0, 1.0, 0, 0, 1, 1.0, -1.0, 1.0, -0.5625, 0.5625]), (1920, 1080))
+    n, spp = cam.x_res * cam.y_res, 16
+    st = torch.cuda.current_stream().cuda_stream
+    rays = torch.zeros(n * 64, dtype=torch.uint8, device="cuda"); hits = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+    nrm = torch.from_numpy(np.ascontiguousarray(normals)).cuda()
+    rt.primary_rays_dev(cam, rays.data_ptr(), stream=st)
+    scene.cast_dev(rays.data_ptr(), n, hits.data_ptr(), stream=st)
+    # ambient occlusion
+    ao = torch.zeros(n * spp * 64, dtype=torch.uint8, device="cuda")
+    occ = torch.zeros(n * spp, dtype=torch.uint8, device="cuda"); occ2 = torch.full_like(occ, 3)
+    scene.ao_rays_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, spp, 2.0, 1, ao.data_ptr(), st)
+    scene.occluded_dev(ao.data_ptr(), n * spp, occ.data_ptr(), st)
+    scene.ao_occlusion_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, spp, 2.0, 1, occ2.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(occ, occ2)
+    frac = float(occ.float().mean())
+    assert 0.02 < frac < 0.3                                   # corners and edges of the room occlude, open floor does not
+    del ao
+    # hard shadows: the light hangs inside the closed room, every surface point that faces it sees it
+    sh = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+    socc = torch.zeros(n, dtype=torch.uint8, device="cuda"); socc2 = torch.full_like(socc, 3)
+    scene.shadow_rays_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, light, sh.data_ptr(), st)
+    scene.occluded_dev(sh.data_ptr(), n, socc.data_ptr(), st)
+    scene.shadow_occlusion_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), n, light, socc2.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(socc, socc2)
+    # soft shadows on the first 64 rows
+    m, NP = 64 * cam.x_res, 100
+    srays = torch.zeros(m * NP * 64, dtype=torch.uint8, device="cuda"); shits = torch.zeros(m * NP * 24, dtype=torch.uint8, device="cuda")
+    fac = torch.zeros(m, dtype=torch.float64, device="cuda"); fac2 = torch.full_like(fac, -1.0)
+    contrib = torch.zeros(m * NP, dtype=torch.uint8, device="cuda")
+    scene.soft_shadow_rays_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), m, light, NP, srays.data_ptr(), st)
+    scene.cast_dev(srays.data_ptr(), m * NP, shits.data_ptr(), stream=st)
+    rt.soft_shadow_factor_dev(hits.data_ptr(), shits.data_ptr(), m, NP, fac.data_ptr(), st)
+    scene.soft_shadow_dev(nrm.data_ptr(), rays.data_ptr(), hits.data_ptr(), m, light, NP, contrib.data_ptr(), fac2.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(fac, fac2)
