@@ -236,3 +236,14 @@ def test_hierarchy_checker_catches_corruptions(tmp_path):
                     "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+def test_scripts_compile():
+    """bench.py, __graft_entry__.py and every tool parse (they only run on the GPU box)."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(root, "tools", "*.py")))
+    assert len(files) > 10
+    for f in files:
+        py_compile.compile(f, doraise=True)
