@@ -320,6 +320,21 @@ int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t
                              uint32_t check_every, rtmi_exchange_fn exchange, void *user, rtmi_solve_stats *stats,
                              void *stream);
 
+/* The same solve for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for hosts that must not
+ * call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  It is
+ * rtmi_radiosity_solve_dev with exchange = NULL over all n rows (same kernels, same results bit for bit), but the solver's
+ * scratch — the second B vector of the Jacobi ping-pong (12·n bytes) and the norm windows — lives in a static device
+ * array inside the library (about 1.6 MiB per GPU, held until the process ends) instead of being hipMalloc'ed per call,
+ * and no HIP events are created (stats->seconds is host wall time around the loop).  It calls no hipMalloc, hipFree or
+ * other allocating routine.  Limits: n <= RTMI_NOALLOC_MAX_N and check_every <= RTMI_NOALLOC_MAX_CHECK_EVERY, otherwise -1
+ * with a message.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two host threads, two
+ * streams) race — serialise them.  What must start at zero (the norm windows) is cleared on the stream by each call. */
+#define RTMI_NOALLOC_MAX_N 131072u
+#define RTMI_NOALLOC_MAX_CHECK_EVERY 64u
+int rtmi_radiosity_solve_noalloc_dev(const float *d_F, uint64_t ld, uint32_t n, const double rho[3], const float *d_E,
+                                     float *d_B, float tol_rel, uint32_t max_sweeps, uint32_t check_every,
+                                     rtmi_solve_stats *stats, void *stream);
+
 /* ---- radiosity: display ------------------------------------------------------------------------------
  * Replaces the pixel loop of Rasterizer::Radiosity_Raster (Render2/rasterizer.cpp:408-470):
  * I(i,j) = ToneMapRadiosity(radiosityHelper->trace_ray(ray, elements)), with

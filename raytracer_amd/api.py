@@ -77,7 +77,7 @@ SYMBOLS = [
     "rtmi_closest_hit", "rtmi_closest_hit_dev", "rtmi_camera_setup", "rtmi_primary_closest_hit_dev",
     "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev", "rtmi_shadow_occlusion_dev", "rtmi_debug_check_hierarchy",
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
-    "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev",
+    "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev", "rtmi_radiosity_solve_noalloc_dev",
     "rtmi_shader_create", "rtmi_shader_destroy", "rtmi_trace_dev", "rtmi_render_frame_dev", "rtmi_tone_map_dev",
     "rtmi_raster_setup", "rtmi_render_frame_sampled_dev", "rtmi_soft_shadow_rays_dev", "rtmi_soft_shadow_factor_dev", "rtmi_soft_shadow_dev",
     "rtmi_scene_file_load", "rtmi_scene_file_free", "rtmi_scene_file_info", "rtmi_scene_file_get",
@@ -130,6 +130,7 @@ def _load():
     L.rtmi_jacobi_sweep_dev.argtypes = [vp, u64, u32, u32, u32, vp, vp, vp, vp, vp, vp]
     L.rtmi_radiosity_solve_dev.argtypes = [vp, u64, u32, u32, u32, vp, vp, vp, C.c_float, u32, u32, vp, vp,
                                            C.POINTER(rtmi_solve_stats), vp]
+    L.rtmi_radiosity_solve_noalloc_dev.argtypes = [vp, u64, u32, vp, vp, vp, C.c_float, u32, u32, C.POINTER(rtmi_solve_stats), vp]
     L.rtmi_shader_create.restype = vp
     L.rtmi_shader_create.argtypes = [vp, vp, vp, u32, vp, u32]
     L.rtmi_shader_destroy.argtypes = [vp]
@@ -581,6 +582,22 @@ class Radiosity:
                                              tile_stride, d_rgb.data_ptr(), d_pix.data_ptr(), torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         return (d_rgb.cpu().numpy().reshape(cam.y_res, cam.x_res, 3), d_pix.cpu().numpy().reshape(cam.y_res, cam.x_res, 3))
+
+
+NOALLOC_MAX_N = 131072            # include/rtmi.h: RTMI_NOALLOC_MAX_N
+NOALLOC_MAX_CHECK_EVERY = 64      # RTMI_NOALLOC_MAX_CHECK_EVERY
+
+
+def radiosity_solve_dev(d_F, ld, n, rho, d_E, d_B, tol_rel, max_sweeps, check_every, stream=0, noalloc=False):
+    """rtmi_radiosity_solve_dev over all rows (no exchange), or its allocation-free twin; returns rtmi_solve_stats."""
+    rho = _np(rho, np.float64, (3,))
+    stats = rtmi_solve_stats()
+    if noalloc:
+        _check(lib.rtmi_radiosity_solve_noalloc_dev(d_F, ld, n, _ptr(rho), d_E, d_B, tol_rel, max_sweeps, check_every, C.byref(stats), stream))
+    else:
+        _check(lib.rtmi_radiosity_solve_dev(d_F, ld, n, 0, n, _ptr(rho), d_E, d_B, tol_rel, max_sweeps, check_every, None, None,
+                                            C.byref(stats), stream))
+    return stats
 
 
 def jacobi_sweep_dev(d_F, ld, n, row0, n_rows, rho, d_E, d_B_old, d_B_new, d_norms, stream=0):

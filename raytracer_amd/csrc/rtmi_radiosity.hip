@@ -5,8 +5,10 @@
 // once to fp32 for storage; the solve streams that fp32 matrix from HBM once per sweep.
 #include "rtmi_host.hpp"
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 struct rtmi_patches {
@@ -579,6 +581,33 @@ static PatchesDev pdev(const rtmi_patches *p) {
 	return d;
 }
 
+// ---- the static scratch of rtmi_radiosity_solve_noalloc_dev -----------------------------------------------------------
+// Device memory that exists from the moment the code object is loaded: callers that must not allocate (HIP graph capture,
+// tight serving loops) get the solver's ping-pong vector and its norm windows from here.  Every GPU the library runs on
+// holds its own copy at its own address; `scratch` itself is only a host-side stand-in for the symbol, so host code uses
+// the per-device pointer hipGetSymbolAddress returns — never the array's name.
+constexpr size_t kScratchTmpBytes = sizeof(float) * 3 * (size_t)RTMI_NOALLOC_MAX_N;                                   // 1.5 MiB
+constexpr size_t kScratchNormBytes = 3 * sizeof(double) * (size_t)kNormSlots * RTMI_NOALLOC_MAX_CHECK_EVERY;           // 96 KiB
+static_assert(kScratchTmpBytes % 256 == 0, "the norms start on a 256-byte boundary");
+static __device__ __align__(256) unsigned char scratch[kScratchTmpBytes + kScratchNormBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static unsigned char *g_scratch_ptr[kMaxDevices]; // per device: the address of ITS copy of `scratch`
+
+static unsigned char *scratch_of_current_device(const char *who) {
+	int dev = -1;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { fail(std::string(who) + ": hipGetDevice failed or device index out of range"); return nullptr; }
+	std::lock_guard<std::mutex> lock(g_scratch_mutex);
+	if (!g_scratch_ptr[dev]) {
+		void *p = nullptr;
+		const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+		if (e != hipSuccess || !p) { fail(std::string(who) + ": hipGetSymbolAddress(scratch) failed: " + hipGetErrorString(e)); return nullptr; }
+		g_scratch_ptr[dev] = static_cast<unsigned char *>(p);
+	}
+	return g_scratch_ptr[dev];
+}
+
 } // namespace rtmi
 
 using namespace rtmi;
@@ -710,37 +739,25 @@ int rtmi_jacobi_sweep_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t ro
 	return sweep_launch(d_F, ld, n, row0, n_rows, rho, d_E, d_B_old, d_B_new, d_norms, 1, stream);
 }
 
-int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3],
-                             const float *d_E, float *d_B, float tol_rel, uint32_t max_sweeps, uint32_t check_every,
-                             rtmi_exchange_fn exchange, void *user, rtmi_solve_stats *stats, void *stream) {
-	const char *who = "rtmi_radiosity_solve_dev";
-	if (!d_F || !rho || !d_E || !d_B) return fail(std::string(who) + ": NULL argument");
-	if (n == 0) return fail(std::string(who) + ": n == 0");
-	if (check_every == 0) check_every = 1;
-	hipStream_t st = (hipStream_t)stream;
+// The Jacobi loop shared by rtmi_radiosity_solve_dev (which allocates d_tmp / d_norms per call) and
+// rtmi_radiosity_solve_noalloc_dev (which brings them from the library's static device array).  e0/e1: HIP events that time
+// the sweeps, or NULL (then stats->seconds is host wall time around the loop, synchronisation included).
+static int solve_loop(const char *who, const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3],
+                      const float *d_E, float *d_B, float tol_rel, uint32_t max_sweeps, uint32_t check_every, rtmi_exchange_fn exchange,
+                      void *user, rtmi_solve_stats *stats, hipStream_t run, float *d_tmp, double *d_norms, uint32_t slots,
+                      hipEvent_t e0, hipEvent_t e1) {
 	const size_t vb = sizeof(float) * 3 * (size_t)n;
-	float *d_tmp = nullptr;
-	// Norms: per sweep of a window of check_every sweeps, `slots` triples (summed on the host; one triple when an exchange
-	// callback reduces them across ranks).  The last sweep's are the ones read.
-	const uint32_t slots = exchange ? 1u : kNormSlots;
 	const size_t nb = 3 * sizeof(double) * slots;
-	double *d_norms = nullptr;
-	hipEvent_t e0 = nullptr, e1 = nullptr;
 	int rc = 0;
-	if (hipMalloc(&d_tmp, vb) != hipSuccess || hipMalloc(&d_norms, nb * check_every) != hipSuccess)
-		rc = fail(std::string(who) + ": hipMalloc failed");
-	if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail(std::string(who) + ": hipEventCreate failed");
-	// (A hipGraph of one window was measured at 3 816 patches: 28.5 vs 28.6 µs per sweep — the launches already run back to
-	// back on the stream and the sweep itself takes the time — and is not used.)
-	hipStream_t run = st;
 	// B_0 = E (Render2/radiosity.cpp:506-509)
-	if (!rc && hipMemcpyAsync(d_B, d_E, vb, hipMemcpyDeviceToDevice, run) != hipSuccess) rc = fail(std::string(who) + ": copy failed");
+	if (hipMemcpyAsync(d_B, d_E, vb, hipMemcpyDeviceToDevice, run) != hipSuccess) return fail(std::string(who) + ": copy failed");
 	float *buf[2] = {d_B, d_tmp};
 	int at = 0; // buf[at] holds the current B
 	uint32_t sweeps = 0;
 	double rel = INFINITY, mx = INFINITY;
-	if (!rc) (void)hipEventRecord(e0, run);
-	// one window: zero its norms, k sweeps; returns the parity after it
+	const auto w0 = std::chrono::steady_clock::now();
+	if (e0) (void)hipEventRecord(e0, run);
+	// one window: zero its norms, k sweeps
 	auto window = [&](uint32_t k, int from, hipStream_t s) -> int {
 		if (hipMemsetAsync(d_norms, 0, nb * k, s) != hipSuccess) return fail(std::string(who) + ": memset failed");
 		for (uint32_t i = 0; i < k; ++i) {
@@ -770,24 +787,75 @@ int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t
 		if (rel <= (double)tol_rel) break;
 	}
 	if (!rc) {
-		(void)hipEventRecord(e1, run);
+		if (e1) (void)hipEventRecord(e1, run);
 		if (at != 0 && hipMemcpyAsync(d_B, buf[at], vb, hipMemcpyDeviceToDevice, run) != hipSuccess) rc = fail(std::string(who) + ": copy failed");
 		if (!rc && hipStreamSynchronize(run) != hipSuccess) rc = fail(std::string(who) + ": synchronize failed: " + hipGetErrorString(hipGetLastError()));
 	}
 	if (!rc && stats) {
 		float ms = 0.f;
-		(void)hipEventElapsedTime(&ms, e0, e1);
+		if (e0 && e1) (void)hipEventElapsedTime(&ms, e0, e1);
+		else ms = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() * 1e3);
 		stats->sweeps = sweeps;
 		stats->rel_change = rel;
 		stats->max_change = mx;
 		stats->seconds = ms * 1e-3;
 		stats->bytes_per_sweep = 4.0 * (double)n_rows * (double)n;
 	}
+	return rc;
+}
+
+static int solve_args(const char *who, const float *d_F, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3], const float *d_E,
+                      const float *d_B, rtmi_exchange_fn exchange) {
+	if (!d_F || !rho || !d_E || !d_B) return fail(std::string(who) + ": NULL argument");
+	if (n == 0) return fail(std::string(who) + ": n == 0");
+	// Without an exchange nobody fills the rows of B this call does not own: a partial row range would iterate on garbage.
+	if (!exchange && (row0 != 0 || n_rows != n)) return fail(std::string(who) + ": a partial row range needs an exchange callback");
+	return 0;
+}
+
+int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3],
+                             const float *d_E, float *d_B, float tol_rel, uint32_t max_sweeps, uint32_t check_every,
+                             rtmi_exchange_fn exchange, void *user, rtmi_solve_stats *stats, void *stream) {
+	const char *who = "rtmi_radiosity_solve_dev";
+	if (solve_args(who, d_F, n, row0, n_rows, rho, d_E, d_B, exchange)) return -1;
+	if (check_every == 0) check_every = 1;
+	float *d_tmp = nullptr;
+	// Norms: per sweep of a window of check_every sweeps, `slots` triples (summed on the host; one triple when an exchange
+	// callback reduces them across ranks).  The last sweep's are the ones read.
+	const uint32_t slots = exchange ? 1u : kNormSlots;
+	double *d_norms = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	int rc = 0;
+	if (hipMalloc(&d_tmp, sizeof(float) * 3 * (size_t)n) != hipSuccess || hipMalloc(&d_norms, 3 * sizeof(double) * slots * check_every) != hipSuccess)
+		rc = fail(std::string(who) + ": hipMalloc failed");
+	if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail(std::string(who) + ": hipEventCreate failed");
+	// (A hipGraph of one window was measured at 3 816 patches: 28.5 vs 28.6 µs per sweep — the launches already run back to
+	// back on the stream and the sweep itself takes the time — and is not used.)
+	if (!rc) rc = solve_loop(who, d_F, ld, n, row0, n_rows, rho, d_E, d_B, tol_rel, max_sweeps, check_every, exchange, user, stats,
+	                         (hipStream_t)stream, d_tmp, d_norms, slots, e0, e1);
 	if (e0) (void)hipEventDestroy(e0);
 	if (e1) (void)hipEventDestroy(e1);
 	if (d_tmp) (void)hipFree(d_tmp);
 	if (d_norms) (void)hipFree(d_norms);
 	return rc;
+}
+
+int rtmi_radiosity_solve_noalloc_dev(const float *d_F, uint64_t ld, uint32_t n, const double rho[3], const float *d_E, float *d_B,
+                                     float tol_rel, uint32_t max_sweeps, uint32_t check_every, rtmi_solve_stats *stats, void *stream) {
+	const char *who = "rtmi_radiosity_solve_noalloc_dev";
+	if (solve_args(who, d_F, n, 0, n, rho, d_E, d_B, nullptr)) return -1;
+	if (n > RTMI_NOALLOC_MAX_N)
+		return fail(std::string(who) + ": n = " + std::to_string(n) + " exceeds RTMI_NOALLOC_MAX_N = " + std::to_string(RTMI_NOALLOC_MAX_N) +
+		            " (the static scratch array); use rtmi_radiosity_solve_dev");
+	if (check_every == 0) check_every = 1;
+	if (check_every > RTMI_NOALLOC_MAX_CHECK_EVERY)
+		return fail(std::string(who) + ": check_every exceeds RTMI_NOALLOC_MAX_CHECK_EVERY = " + std::to_string(RTMI_NOALLOC_MAX_CHECK_EVERY));
+	unsigned char *base = scratch_of_current_device(who);
+	if (!base) return -1;
+	float *d_tmp = reinterpret_cast<float *>(base);                       // B ping-pong partner: fully written by sweep 1 before it is read
+	double *d_norms = reinterpret_cast<double *>(base + kScratchTmpBytes); // zeroed per window by solve_loop
+	return solve_loop(who, d_F, ld, n, 0, n, rho, d_E, d_B, tol_rel, max_sweeps, check_every, nullptr, nullptr, stats, (hipStream_t)stream,
+	                  d_tmp, d_norms, kNormSlots, nullptr, nullptr);
 }
 
 int rtmi_radiosity_trace_dev(rtmi_patches *P, const double *d_vertex_radiosity, const rtmi_ray *d_rays, uint64_t n, double *d_rgb,
