@@ -1,0 +1,538 @@
+// librtmi — radiosity: the form-factor build (include/rtmi.h: rtmi_form_factors_dev), gfx950 only.
+//
+// Reference: Radiosity::findFormFactor's fill loops (Render2/radiosity.cpp:379-403) over findFormFactorTerm (:305-333),
+// isVisibleXiToXj (:231-262) and findFormFactorTermWithLight (:264-303).  Every quantity that decides a bit of F is
+// evaluated in double in the reference's operation order (the sample points come from the counter-based generator of
+// rtmi_rad_device.hpp, which the oracle restates), so F equals the oracle's bit for bit.
+//
+// What is new here is HOW the closest hit of a visibility ray is found.  A form-factor ray is not an arbitrary ray: it
+// leaves patch i and is aimed at a point of patch j, and both are leaves of the hierarchy whose root-to-leaf paths are
+// known.  Every other triangle lies in exactly one subtree hanging off one of those two paths (a "sibling" of the path).
+// So instead of descending from the root — about forty box-pair tests per ray in a closed room, nearly all of them spent
+// rediscovering the two leaves — the kernel
+//   1. tests triangle j first (exact Möller–Trumbore): that bounds the ray at its target,
+//   2. tests the ray against the sibling boxes along the two paths, and walks into a sibling's subtree only where the box
+//      is hit (the ordinary stack traversal, rtmi_device.hpp: node_step),
+//   3. reads the verdict off the closest hit exactly as the reference does.
+// Skipping a box test is always safe (nothing is culled by it), every sibling box is the same conservative box the
+// root traversal would have tested, and the closest hit with its tie rule (smaller triangle id) does not depend on the
+// order in which triangles are met: the hit record — hence F — is the root traversal's, bit for bit.  When triangle j
+// itself is not hit (a sample point on its very edge) the ray falls back to the root traversal.
+// The ten sample rays of a pair (i, j) are nearly parallel, so step 2 is done once per pair against the BEAM between the
+// two patches' bounds (one conservative slab test per sibling box); the per-ray exact test runs only for the survivors —
+// in a room, the other triangle of each quad.
+//
+// Work layout: a wave owns 64 patches j that are neighbours in depth-first leaf order (coherent targets, and their paths
+// share their upper parts) and walks a band of rows i; everything that depends on i alone — vertices, normal, path — is
+// wave-uniform and lives in scalar registers.  A launch is (groups of j) × (bands of i) workgroups; the tables one
+// workgroup touches (its four groups' paths, the band's paths) are a few hundred KB and stay in its XCD's L2.
+#include "rtmi_rad_device.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace rtmi {
+
+// One sibling along a root-to-leaf path: its fp32 bounds (the quantised box of the binary node, which contains the
+// triangles' bounds) and its reference (inner node >= 0, leaf < 0 as in QNode).  32 B = two 16-byte loads.
+struct __attribute__((aligned(16))) ChainEntry {
+	float lo[3];
+	int32_t ref;
+	float hi[3];
+	uint32_t level;
+};
+// Per patch (original id): where its path's siblings start in the chain array, the path itself (bit L = went right at
+// level L), its length, and the position of its triangle in the leaf-ordered array.
+struct __attribute__((aligned(16))) PatchMeta {
+	uint32_t chain_off, path, depth, leafpos;
+};
+struct FFTables {
+	const ChainEntry *chain;
+	const PatchMeta *meta;
+	const uint32_t *dfs;
+	uint32_t n_groups;
+};
+
+// Slab test against an fp32 box widened per axis by a pad folded into the addends: t(lo plane) = lo·i − (o + pad)·i,
+// t(hi plane) = hi·i − (o − pad)·i (the pad dominates every rounding on the way).
+struct RayS {
+	float ix, iy, iz;
+	float lx, ly, lz; // −(o + pad)·i
+	float hx, hy, hz; // −(o − pad)·i
+};
+__device__ __forceinline__ RayS make_rays(float ox, float oy, float oz, float dx, float dy, float dz, float px, float py, float pz) {
+	RayS r;
+	r.ix = safe_rcp(dx); r.iy = safe_rcp(dy); r.iz = safe_rcp(dz);
+	r.lx = -(ox + px) * r.ix; r.ly = -(oy + py) * r.iy; r.lz = -(oz + pz) * r.iz;
+	r.hx = -(ox - px) * r.ix; r.hy = -(oy - py) * r.iy; r.hz = -(oz - pz) * r.iz;
+	return r;
+}
+__device__ __forceinline__ bool slab_box(const float4 a, const float4 b, const RayS &r, float tmax) {
+	const float tlx = fmaf(a.x, r.ix, r.lx), thx = fmaf(b.x, r.ix, r.hx);
+	const float tly = fmaf(a.y, r.iy, r.ly), thy = fmaf(b.y, r.iy, r.hy);
+	const float tlz = fmaf(a.z, r.iz, r.lz), thz = fmaf(b.z, r.iz, r.hz);
+	const float tn = fmaxf(fmaxf(fminf(tlx, thx), fminf(tly, thy)), fmaxf(fminf(tlz, thz), 0.0f));
+	const float tf = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fminf(fmaxf(tlz, thz), tmax));
+	return tn <= tf;
+}
+
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, off, 64));
+	return uniform_u32(x);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) x = min(x, (uint32_t)__shfl_xor((int)x, off, 64));
+	return uniform_u32(x);
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) x |= (uint32_t)__shfl_xor((int)x, off, 64);
+	return uniform_u32(x);
+}
+
+// fp32 bounds of a patch (three vertices, doubles): nearest rounding — the beam test's margin covers the half ulp
+__device__ __forceinline__ void patch_bounds(const double *v, float lo[3], float hi[3]) {
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {
+		const float p = (float)v[a], q = (float)v[3 + a], r = (float)v[6 + a];
+		lo[a] = fminf(p, fminf(q, r));
+		hi[a] = fmaxf(p, fmaxf(q, r));
+	}
+}
+
+// The ordinary stack traversal (binary nodes), started from whatever a lane holds: `cur` (a node, a leaf reference, or
+// kSentinel) and `sp` entries on its stack.  Closest hit with the tie rule; vote-scheduled like trace(): per iteration the
+// wave takes ONE node step or ONE triangle step.
+__device__ __forceinline__ void trace_from(const SceneDev &S, const RayF &rf, double ox, double oy, double oz, double dx, double dy, double dz,
+                                           double &best, uint32_t &pos, int cur, int sp, int *stack) {
+	float tbest = f32_above(best);
+	uint32_t tk = 0, tend = 0;
+	for (uint32_t guard = 0; guard < kGuard; ++guard) {
+		if (cur < 0 && cur != kSentinel && cur != kLeaf) {
+			const uint32_t code = ~(uint32_t)cur;
+			tk = code >> 3;
+			tend = tk + (code & 7u) + 1u;
+			cur = kLeaf;
+		}
+		const int n_node = __popcll(__ballot(cur >= 0)), n_leaf = __popcll(__ballot(cur == kLeaf));
+		if (n_node + n_leaf == 0) break;
+		if (n_node >= n_leaf) {
+			if (cur >= 0) cur = node_step(S, rf, tbest, cur, sp, stack);
+		} else if (cur == kLeaf) {
+			const GTri T = load_tri(S.tris + tk);
+			double u = 0.0, v = 0.0;
+			const double t = mt_exact(ox, oy, oz, dx, dy, dz, T, u, v);
+			// strict minimum; equal t -> smaller original id (Render2/object.cpp:155 keeps the first of its in-order scan)
+			if (t > 0.0 && (best > t || (t == best && pos != RTMI_MISS && T.orig < S.tris[pos].orig))) {
+				best = t;
+				tbest = f32_above(best);
+				pos = tk;
+			}
+			++tk;
+			if (tk == tend) {
+				if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+				else cur = kSentinel;
+			}
+		}
+	}
+}
+
+// Render2/radiosity.cpp:264-303 (findFormFactorTermWithLight) for patch i
+__device__ __forceinline__ double light_term(const SceneDev &S, const PatchesDev &P, uint32_t i, D3 C, uint32_t light_samples, uint64_t seed,
+                                             uint32_t flags, int *stack) {
+	const double *ei = P.verts + 9 * (size_t)i;
+	const D3 ni = d3(P.normals[3 * (size_t)i], P.normals[3 * (size_t)i + 1], P.normals[3 * (size_t)i + 2]);
+	const bool mean = (flags & RTMI_FF_LIGHT_MEAN) != 0;
+	double ff = 0.0;
+	// the reference zeroes its accumulator inside the loop (:276): only the last sample survives
+	for (uint32_t k = mean ? 0u : light_samples - 1; k < light_samples; ++k) {
+		const D3 x = sample_point(ei, seed, i, kLightStream, k, 0);
+		const D3 dir = unit(C - x);
+		const D3 org = x + (kEpsilon * ni);
+		const double L = sqrt(len2(C - x));
+		const double tmp = ((1.0 / (4.0 * kPi)) * (dot(dir, ni) / (L * L)));
+		if (tmp > 0.0) { // only a positive term is ever added (:297-299): the ray is needed for those alone
+			HitP h;
+			trace<true, false, false>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h);
+			if (h.pos == RTMI_MISS) ff += tmp;
+		}
+	}
+	return light_samples ? ff / ((double)light_samples) : 0.0;
+}
+
+// Column n_patches (the light) of rows [row0, row0 + n_rows), and the light's own row: one lane per row.
+RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx, double cy, double cz, uint32_t light_samples, uint64_t seed,
+                                             uint32_t flags, uint32_t row0, uint32_t n_rows, float *__restrict__ F, uint64_t ld) {
+	extern __shared__ int stack_all[]; // rtmi_scene::stack_bytes_binary
+	const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+	if (r >= n_rows) return;
+	const uint32_t i = row0 + r;
+	double out = 0.0;
+	if (i < P.n) out = light_term(S, P, i, d3(cx, cy, cz), light_samples, seed, flags, stack_all + threadIdx.x);
+	F[(uint64_t)r * ld + P.n] = (float)out; // the light's own entry (:382) is 0
+}
+
+#ifndef RTMI_FF_WAVES
+#define RTMI_FF_WAVES 4
+#endif
+// Workgroup = ONE group of 64 patches j (blockIdx.x); its four waves take four consecutive bands of rows i, so the group's
+// per-lane tables are fetched once per workgroup and shared through the L1.  Columns j < n_patches only; the light's row
+// (i == n_patches) is zero (:391-393), the diagonal too (:382).
+// stack: 2·(depth + 1) entries per lane — up to depth + 1 sibling subtrees waiting, and the traversal inside one of them.
+RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDev P, FFTables T, uint32_t samples, uint64_t seed,
+                                                           uint32_t row0, uint32_t n_rows, uint32_t band_rows, float margin,
+                                                           uint32_t pend_cap, float *__restrict__ F, uint64_t ld) {
+	extern __shared__ int stack_all[];
+	int *stack = stack_all + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t g = blockIdx.x;
+	const uint32_t band = blockIdx.y * (kBlock / 64u) + uniform_u32(threadIdx.x >> 6);
+	const uint32_t r_begin = band * band_rows, r_end = min(n_rows, r_begin + band_rows);
+	if (r_begin >= n_rows) return; // whole wave
+	const uint32_t j0 = T.dfs[(size_t)g * 64u]; // a group's first slot is always a patch
+	const uint32_t j = T.dfs[(size_t)g * 64u + lane];
+	const bool valid_j = j != RTMI_MISS;
+	const uint32_t jj = valid_j ? j : j0;
+	const PatchMeta mj = T.meta[jj];
+	const PatchMeta m0 = T.meta[j0]; // wave-uniform
+	const double *ejp = P.verts + 9 * (size_t)jj;
+	const D3 nj = d3(P.normals[3 * (size_t)jj], P.normals[3 * (size_t)jj + 1], P.normals[3 * (size_t)jj + 2]);
+	const double area_j = P.area[jj];
+	const double area_term = area_j / (int)samples; // :319, the same for every sample
+	float blo[3], bhi[3];
+	patch_bounds(ejp, blo, bhi);
+	const ChainEntry *chain_j = T.chain + mj.chain_off;
+	const ChainEntry *chain_0 = T.chain + m0.chain_off;
+	// The group's paths agree on their first `common` levels: those siblings are the same for every lane (read once per wave
+	// through the scalar cache, chain_0); below, each lane has its own.
+	const uint32_t pdiff = mj.path ^ m0.path;
+	const uint32_t common = wave_min_u32(min(mj.depth, pdiff ? (uint32_t)(__ffs((int)pdiff) - 1) : 32u));
+	const uint32_t max_dj = wave_max_u32(mj.depth);
+	for (uint32_t r = r_begin; r < r_end; ++r) {
+		const uint32_t i = row0 + r; // wave-uniform
+		double out = 0.0;
+		if (i < P.n) {
+			const PatchMeta mi = T.meta[i];
+			const double *ei = P.verts + 9 * (size_t)i;
+			const D3 ni = d3(P.normals[3 * (size_t)i], P.normals[3 * (size_t)i + 1], P.normals[3 * (size_t)i + 2]);
+			const ChainEntry *chain_i = T.chain + mi.chain_off;
+			const bool pair = valid_j && jj != i;
+			// ---- the beam between the two patches against the siblings of both paths: once per pair ----------------
+			// Every ray of the pair runs from a point within 1e-5 of patch i's bounds to its hit on triangle j, within
+			// rounding of patch j's bounds; such a segment stays within max(half extents) of the line between the two
+			// boxes' centres.  `margin` covers the 1e-5, the per-ray pad of the exact test and all fp32 roundings.
+			// mask_i / mask_j: bit L = the sibling at level L of path i / path j may be met by a ray of this pair.
+			uint32_t mask_i = 0u, mask_j = 0u;
+			const uint32_t xij = mi.path ^ mj.path, xi0 = mi.path ^ m0.path;
+			const uint32_t lca = (pair && xij) ? (uint32_t)(__ffs((int)xij) - 1) : 0u;     // first level where the paths part
+			const uint32_t lca0 = xi0 ? (uint32_t)(__ffs((int)xi0) - 1) : 32u;              // ... for the group's first patch (uniform)
+			{
+				float alo[3], ahi[3];
+				patch_bounds(ei, alo, ahi);
+				const float cax = 0.5f * (alo[0] + ahi[0]), cay = 0.5f * (alo[1] + ahi[1]), caz = 0.5f * (alo[2] + ahi[2]);
+				const float cbx = 0.5f * (blo[0] + bhi[0]), cby = 0.5f * (blo[1] + bhi[1]), cbz = 0.5f * (blo[2] + bhi[2]);
+				const float px = fmaxf(ahi[0] - alo[0], bhi[0] - blo[0]) * 0.5f + margin;
+				const float py = fmaxf(ahi[1] - alo[1], bhi[1] - blo[1]) * 0.5f + margin;
+				const float pz = fmaxf(ahi[2] - alo[2], bhi[2] - blo[2]) * 0.5f + margin;
+				const RayS beam = make_rays(cax, cay, caz, cbx - cax, cby - cay, cbz - caz, px, py, pz);
+				for (uint32_t L = 0; L < mi.depth; ++L) { // wave-uniform entries
+					const float4 a = *reinterpret_cast<const float4 *>(chain_i + L), b = *(reinterpret_cast<const float4 *>(chain_i + L) + 1);
+					if (pair && L != lca && slab_box(a, b, beam, 1.0f)) mask_i |= 1u << L;
+				}
+				// path j above the group's common depth: if path i parts from the group there (lca0 < common), every lane's
+				// lca is lca0 and the levels between are the group's shared siblings
+				for (uint32_t L = lca0 + 1u; L < common; ++L) { // wave-uniform entries (empty when lca0 >= common)
+					const float4 a = *reinterpret_cast<const float4 *>(chain_0 + L), b = *(reinterpret_cast<const float4 *>(chain_0 + L) + 1);
+					if (pair && slab_box(a, b, beam, 1.0f)) mask_j |= 1u << L;
+				}
+				for (uint32_t L = common; L < max_dj; ++L) { // per-lane entries
+					if (pair && L > lca && L < mj.depth) {
+						const float4 a = *reinterpret_cast<const float4 *>(chain_j + L), b = *(reinterpret_cast<const float4 *>(chain_j + L) + 1);
+						if (slab_box(a, b, beam, 1.0f)) mask_j |= 1u << L;
+					}
+				}
+			}
+			const uint32_t low = common >= 32u ? ~0u : ((1u << common) - 1u);
+			const uint32_t um_i = wave_or_u32(mask_i), um_j = wave_or_u32(mask_j & low);
+			const uint32_t own_j = mask_j & ~low;
+			// ---- the samples of the pair, in the reference's order (:309-330) --------------------------------------
+			const uint64_t h0 = mix64(seed ^ (((uint64_t)i << 32) | jj));
+			double ff = 0.0;
+			for (uint32_t k = 0; k < samples; ++k) {
+				bool shoot = false;
+				D3 xj = d3(0, 0, 0), dir = d3(0, 0, 1), org = d3(0, 0, 0);
+				double c1 = 0.0, c2 = 0.0, dist2 = 0.0;
+				if (pair) {
+					const D3 xi = sample_point_h(ei, h0, k, 0);
+					xj = sample_point_h(ejp, h0, k, 1);
+					// Unit(xj − xi) once: the reference evaluates it three times (:235, :317, and Unit(xi − xj) = its exact
+					// negation, :318), and dist2 = (xi−xj)·(xi−xj) is the squared length inside it — same IEEE operations.
+					const D3 vec = xj - xi;
+					dist2 = len2(vec);
+					dir = dist2 > 0.0 ? vec / sqrt(dist2) : d3(0, 0, 0);
+					// A sample adds to the sum only if delF > 0, i.e. both cosines are positive (:320-324) — whatever the
+					// visibility ray says.  So the ray is shot only for those samples.
+					c1 = dot(dir, ni);
+					c2 = -dot(dir, nj);
+					org = xi + (kEpsilon * dir);
+					shoot = c1 > 0.0 && c2 > 0.0;
+				}
+				if (__ballot(shoot) == 0ull) continue;
+				double best = RTMI_INFINITY;
+				uint32_t pos = RTMI_MISS;
+				int cur = kSentinel, sp = 0;
+				bool walk = false;     // this lane's ray is bounded by its hit on triangle j: siblings of the two paths
+				bool from_root = false; // ... or not (or too many siblings are hit): the ordinary traversal
+				if (shoot) {
+					// triangle j first: e1 = v2 − v1, e2 = v3 − v1 are the IEEE subtractions the scene stores (object.cpp:36-37)
+					GTri Tj;
+#pragma unroll
+					for (int a = 0; a < 3; ++a) { Tj.v0[a] = ejp[a]; Tj.e1[a] = ejp[3 + a] - ejp[a]; Tj.e2[a] = ejp[6 + a] - ejp[a]; }
+					double u = 0.0, v = 0.0;
+					const double t = mt_exact(org.x, org.y, org.z, dir.x, dir.y, dir.z, Tj, u, v);
+					if (t > 0.0) { best = t; pos = mj.leafpos; walk = true; }
+					else from_root = true;
+				}
+				const float tb0 = f32_above(best);
+				RayS rs;
+				{
+					const float fx = (float)org.x, fy = (float)org.y, fz = (float)org.z;
+					const float pad = 3.814697265625e-06f * (S.absmax + fmaxf(fabsf(fx), fmaxf(fabsf(fy), fabsf(fz)))) + 1e-30f; // as make_rayf
+					rs = make_rays(fx, fy, fz, (float)dir.x, (float)dir.y, (float)dir.z, pad, pad, pad);
+				}
+				auto push = [&](int ref) {
+					if ((uint32_t)sp < pend_cap) { stack[sp * kBlock] = ref; ++sp; }
+					else from_root = true;
+				};
+				// Triangle i lies 1e-5 BEHIND the origin along the ray (t = −1e-5 up to rounding of relative size 1e-15/c1): it
+				// cannot be hit unless the ray all but grazes it — then it is tested like any other.
+				if (walk && (!(c1 > 1e-3) || S.absmax > 1e4f)) push((int)~(mi.leafpos << 3));
+				// the siblings the beam met, against THIS ray (exact slab test, bounded by the hit on j)
+				for (uint32_t m = um_i; m; m &= m - 1u) { // wave-uniform
+					const uint32_t L = (uint32_t)__builtin_ctz(m);
+					const float4 a = *reinterpret_cast<const float4 *>(chain_i + L), b = *(reinterpret_cast<const float4 *>(chain_i + L) + 1);
+					if (walk && ((mask_i >> L) & 1u) && slab_box(a, b, rs, tb0)) push(__float_as_int(a.w));
+				}
+				for (uint32_t m = um_j; m; m &= m - 1u) { // wave-uniform
+					const uint32_t L = (uint32_t)__builtin_ctz(m);
+					const float4 a = *reinterpret_cast<const float4 *>(chain_0 + L), b = *(reinterpret_cast<const float4 *>(chain_0 + L) + 1);
+					if (walk && ((mask_j >> L) & 1u) && slab_box(a, b, rs, tb0)) push(__float_as_int(a.w));
+				}
+				for (uint32_t m = walk ? own_j : 0u; __ballot(m != 0u) != 0ull; m &= m - 1u) { // per lane
+					if (m) {
+						const uint32_t L = (uint32_t)__builtin_ctz(m);
+						const float4 a = *reinterpret_cast<const float4 *>(chain_j + L), b = *(reinterpret_cast<const float4 *>(chain_j + L) + 1);
+						if (slab_box(a, b, rs, tb0)) push(__float_as_int(a.w));
+					}
+				}
+				if (from_root) { best = RTMI_INFINITY; pos = RTMI_MISS; sp = 0; cur = S.root_ref; }
+				else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+				if (__ballot(cur != kSentinel) != 0ull) {
+					const RayF rf = make_rayf(S, org.x, org.y, org.z, dir.x, dir.y, dir.z);
+					trace_from(S, rf, org.x, org.y, org.z, dir.x, dir.y, dir.z, best, pos, cur, sp, stack);
+				}
+				if (shoot && pos != RTMI_MISS) {
+					// hit.point = o + (d·((v1 − o)·n)) / (n·d) with the HIT triangle's first vertex and normal (object.cpp:23),
+					// visible ⇔ |hit.point − xj| < 1e-5 ∧ d·n_j < 0 (radiosity.cpp:249-252; the latter is c2 > 0)
+					const GTri &Th = S.tris[pos];
+					const double *np = P.normals + 3 * (size_t)Th.orig;
+					const D3 n = d3(np[0], np[1], np[2]);
+					const D3 v1 = d3(Th.v0[0], Th.v0[1], Th.v0[2]);
+					const D3 p = org + (dot(v1 - org, n) * dir) / dot(n, dir);
+					if (sqrt(len2(p - xj)) < kEpsilon) {
+						const double cosFactor = c1 * c2;
+						const double delF = cosFactor / ((kPi * dist2) + area_term);
+						if (delF > 0.0) ff += delF;
+					}
+				}
+			}
+			ff = ff / ((double)samples);
+			out = ff * area_j;
+		}
+		if (valid_j) F[(uint64_t)r * ld + j] = (float)out;
+	}
+}
+
+// ---- the round-1 kernel, kept as a cross-check (RTMI_FF_KERNEL=flat; tests compare the two) -----------------------------
+// One lane per matrix entry (i, j), j fastest; every ray descends from the root.
+RTMI_TRAVERSAL_KERNEL_W(7) void k_form_factors_flat(SceneDev S, PatchesDev P, uint32_t samples, uint64_t seed, uint32_t row0,
+                                                    uint32_t n_rows, float *__restrict__ F, uint64_t ld) {
+	extern __shared__ int stack_all[];
+	int *stack = stack_all + threadIdx.x;
+	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (idx >= (uint64_t)n_rows * P.n) return;
+	const uint32_t r = (uint32_t)(idx / P.n), j = (uint32_t)(idx % P.n), i = row0 + r;
+	double out = 0.0;
+	if (i < P.n && i != j) {
+		const double *ei = P.verts + 9 * (size_t)i, *ejp = P.verts + 9 * (size_t)j;
+		const D3 ni = d3(P.normals[3 * (size_t)i], P.normals[3 * (size_t)i + 1], P.normals[3 * (size_t)i + 2]);
+		const D3 nj = d3(P.normals[3 * (size_t)j], P.normals[3 * (size_t)j + 1], P.normals[3 * (size_t)j + 2]);
+		const double area_j = P.area[j];
+		const double area_term = area_j / (int)samples;
+		double ff = 0.0;
+		for (uint32_t k = 0; k < samples; ++k) {
+			const D3 xi = sample_point(ei, seed, i, j, k, 0), xj = sample_point(ejp, seed, i, j, k, 1);
+			const D3 vec = xj - xi;
+			const double dist2 = len2(vec);
+			const D3 dir = dist2 > 0.0 ? vec / sqrt(dist2) : d3(0, 0, 0);
+			const double c1 = dot(dir, ni);
+			const double c2 = -dot(dir, nj);
+			if (c1 > 0.0 && c2 > 0.0 && visible_along(S, P, j, xi + (kEpsilon * dir), dir, xj, stack)) {
+				const double cosFactor = c1 * c2;
+				const double delF = cosFactor / ((kPi * dist2) + area_term);
+				if (delF > 0.0) ff += delF;
+			}
+		}
+		ff = ff / ((double)samples);
+		out = ff * area_j;
+	}
+	F[(uint64_t)r * ld + j] = (float)out;
+}
+
+// ---- host: the path tables ---------------------------------------------------------------------------------------------
+static float f32_below(double x) { float f = (float)x; return (double)f > x ? std::nextafterf(f, -INFINITY) : f; }
+static float f32_above_h(double x) { float f = (float)x; return (double)f < x ? std::nextafterf(f, INFINITY) : f; }
+
+// Walks the binary hierarchy as the device holds it and writes, per patch, the siblings along its path.
+struct TableWalk {
+	const rtmi_scene *s;
+	std::vector<QNode> nodes;
+	std::vector<GTri> tris;
+	std::vector<ChainEntry> chain, sib; // sib[L] = the sibling at level L of the path being walked
+	std::vector<PatchMeta> meta;
+	std::vector<uint32_t> dfs;
+	std::vector<uint8_t> seen;
+	bool bad = false;
+	double plane(uint32_t q, int a) const { return (double)s->dev.qlo[a] + (double)q * (double)s->dev.qstep[a]; }
+	void walk(int32_t ref, uint32_t path, uint32_t depth) {
+		if (bad) return;
+		if (ref < 0) { // a leaf: ONE triangle (rtmi_scene_create builds leaves of one)
+			const uint32_t code = ~(uint32_t)ref, pos = code >> 3;
+			if ((code & 7u) != 0u || pos >= tris.size()) { bad = true; return; }
+			const uint32_t id = tris[pos].orig;
+			if (id >= meta.size() || seen[id]) { bad = true; return; }
+			seen[id] = 1;
+			meta[id].chain_off = (uint32_t)chain.size();
+			meta[id].path = path;
+			meta[id].depth = depth;
+			meta[id].leafpos = pos;
+			chain.insert(chain.end(), sib.begin(), sib.end());
+			dfs.push_back(id);
+			return;
+		}
+		if ((size_t)ref >= nodes.size() || depth >= 31u) { bad = true; return; }
+		const QNode &q = nodes[ref];
+		const uint32_t w[2][3] = {{q.a.x, q.a.y, q.a.z}, {q.a.w, q.b.x, q.b.y}};
+		const int32_t child[2] = {(int32_t)q.b.z, (int32_t)q.b.w};
+		ChainEntry e[2];
+		for (int c = 0; c < 2; ++c) {
+			for (int a = 0; a < 3; ++a) { // the box the traversal kernels test for this child, as fp32 planes that contain it
+				e[c].lo[a] = f32_below(plane(w[c][a] & 0xffffu, a));
+				e[c].hi[a] = f32_above_h(plane(w[c][a] >> 16, a));
+			}
+			e[c].ref = child[c];
+			e[c].level = depth;
+		}
+		sib.push_back(e[1]); // walking into child 0, the other child is the sibling at this level
+		walk(child[0], path, depth + 1u);
+		sib.back() = e[0];
+		walk(child[1], path | (1u << depth), depth + 1u);
+		sib.pop_back();
+	}
+};
+
+static int build_ff_tables(rtmi_patches *P, const char *who) {
+	std::lock_guard<std::mutex> lock(P->ff_mutex);
+	if (P->ff_ready) return 0;
+	const rtmi_scene *s = P->scene;
+	const uint32_t n = P->n;
+	TableWalk W;
+	W.s = s;
+	W.nodes.resize((size_t)s->info.n_nodes);
+	W.tris.resize(n);
+	W.meta.resize(n);
+	W.seen.assign(n, 0);
+	if ((!W.nodes.empty() && hipMemcpy(W.nodes.data(), s->dev.nodes, W.nodes.size() * sizeof(QNode), hipMemcpyDeviceToHost) != hipSuccess) ||
+	    hipMemcpy(W.tris.data(), s->dev.tris, (size_t)n * sizeof(GTri), hipMemcpyDeviceToHost) != hipSuccess)
+		return fail(std::string(who) + ": reading the hierarchy back failed");
+	W.dfs.reserve(((size_t)n + 63) / 64 * 64);
+	W.walk(s->dev.root_ref, 0u, 0u);
+	if (W.bad || W.dfs.size() != n) return fail(std::string(who) + ": the hierarchy is not a binary tree over the patches with one triangle per leaf");
+	if (W.chain.size() > 0xffffffffull) return fail(std::string(who) + ": path table too large");
+	const uint32_t n_groups = (n + 63u) / 64u;
+	W.dfs.resize((size_t)n_groups * 64u, RTMI_MISS);
+	if (W.chain.empty()) W.chain.emplace_back(); // a one-patch scene has no siblings; keep the pointer valid
+	void *d_chain = nullptr, *d_meta = nullptr;
+	uint32_t *d_dfs = nullptr;
+	bool ok = hipMalloc(&d_chain, W.chain.size() * sizeof(ChainEntry)) == hipSuccess && hipMalloc(&d_meta, (size_t)n * sizeof(PatchMeta)) == hipSuccess &&
+	          hipMalloc(&d_dfs, W.dfs.size() * sizeof(uint32_t)) == hipSuccess;
+	ok = ok && hipMemcpy(d_chain, W.chain.data(), W.chain.size() * sizeof(ChainEntry), hipMemcpyHostToDevice) == hipSuccess &&
+	     hipMemcpy(d_meta, W.meta.data(), (size_t)n * sizeof(PatchMeta), hipMemcpyHostToDevice) == hipSuccess &&
+	     hipMemcpy(d_dfs, W.dfs.data(), W.dfs.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+	if (!ok) {
+		if (d_chain) (void)hipFree(d_chain);
+		if (d_meta) (void)hipFree(d_meta);
+		if (d_dfs) (void)hipFree(d_dfs);
+		return fail(std::string(who) + ": device allocation or upload of the path tables failed");
+	}
+	P->d_chain = d_chain; P->d_meta = d_meta; P->d_dfs = d_dfs;
+	P->n_groups = n_groups;
+	P->chain_entries = W.chain.size();
+	P->ff_ready = true;
+	return 0;
+}
+
+} // namespace rtmi
+
+using namespace rtmi;
+
+extern "C" {
+
+int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t samples, uint32_t light_samples,
+                          uint64_t seed, uint32_t flags, uint32_t row0, uint32_t n_rows, float *d_F, uint64_t ld,
+                          void *stream) {
+	const char *who = "rtmi_form_factors_dev";
+	if (check_patches(P, who)) return -1;
+	const uint32_t n = P->n + (light_center ? 1u : 0u);
+	if (n_rows == 0) return 0;
+	if (!d_F) return fail(std::string(who) + ": d_F is NULL");
+	if (samples == 0) return fail(std::string(who) + ": samples must be >= 1");
+	if ((uint64_t)row0 + n_rows > n) return fail(std::string(who) + ": row range exceeds n");
+	if (ld < n) return fail(std::string(who) + ": ld < n");
+	hipStream_t st = (hipStream_t)stream;
+	const rtmi_scene *s = P->scene;
+	const char *mode = std::getenv("RTMI_FF_KERNEL");
+	if (mode && std::strcmp(mode, "flat") == 0) { // the round-1 kernel: every ray from the root (cross-check)
+		const uint64_t total = (uint64_t)n_rows * P->n, grid = (total + kBlock - 1) / kBlock;
+		if (grid > 0x7fffffffull) return fail(std::string(who) + ": too many entries for one launch; shard the rows");
+		hipLaunchKernelGGL(k_form_factors_flat, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes_binary, st, s->dev, pdev(P), samples, seed, row0,
+		                   n_rows, d_F, ld);
+	} else {
+		if (build_ff_tables(P, who)) return -1;
+		uint32_t band = std::max(1u, env_uint("RTMI_FF_BAND", 64));
+		while ((n_rows + band - 1) / band > 4u * 65535u) band *= 2;
+		const FFTables T = {static_cast<const ChainEntry *>(P->d_chain), static_cast<const PatchMeta *>(P->d_meta), P->d_dfs, P->n_groups};
+		// beam margin: the 1e-5 origin offset, the exact test's per-ray pad (<= 2^-17·absmax) and the fp32 roundings of both
+		const float margin = 1.52587890625e-05f * s->dev.absmax + 1e-4f;
+		const uint32_t n_bands = (n_rows + band - 1) / band;
+		const dim3 grid(P->n_groups, (n_bands + kBlock / 64 - 1) / (kBlock / 64));
+		const uint32_t pend_cap = s->info.max_depth + 1u; // siblings that may wait on a lane's stack; as many entries again serve the traversal
+		const uint32_t lds = 2u * (s->info.max_depth + 1u) * kBlock * (uint32_t)sizeof(int);
+		hipLaunchKernelGGL(k_form_factors, grid, dim3(kBlock), lds, st, s->dev, pdev(P), T, samples, seed, row0, n_rows, band, margin, pend_cap,
+		                   d_F, ld);
+	}
+	if (launch_check(who)) return -1;
+	if (light_center) {
+		hipLaunchKernelGGL(k_ff_light_column, dim3((n_rows + kBlock - 1) / kBlock), dim3(kBlock), s->stack_bytes_binary, st, s->dev, pdev(P),
+		                   light_center[0], light_center[1], light_center[2], light_samples, seed, flags, row0, n_rows, d_F, ld);
+		if (launch_check(who)) return -1;
+	}
+	return 0;
+}
+
+} // extern "C"

@@ -18,9 +18,21 @@ struct rtmi_scene {
 	int n_cus;
 	uint32_t n_objects; // 1 + the largest tri_object seen at creation (materials are looked up by it)
 	double *d_v1_orig; // n_tris × 3: triVert1 of every triangle in ORIGINAL order (hit points, object.cpp:23)
+	uint64_t xyz_hash; // of the vertex array the scene was built from (rtmi_patches_create must be handed the same one)
 };
 
 namespace rtmi {
+// 64-bit digest of a vertex array (bit patterns; not cryptographic): tells "the same array" from another one
+inline uint64_t hash_doubles(const double *p, uint64_t n) {
+	uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+	for (uint64_t k = 0; k < n; ++k) {
+		uint64_t w;
+		__builtin_memcpy(&w, p + k, 8);
+		h = (h ^ w) * 0xBF58476D1CE4E5B9ull;
+		h ^= h >> 29;
+	}
+	return h;
+}
 constexpr uint32_t kQueueSlots = 256;
 extern thread_local std::string g_err;
 int fail(const std::string &msg);        // records msg for rtmi_last_error(), returns -1

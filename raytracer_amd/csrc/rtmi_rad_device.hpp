@@ -1,0 +1,103 @@
+// Device-side helpers shared by the radiosity translation units (rtmi_radiosity.hip: visibility, solve, display;
+// rtmi_formfactor.hip: the form-factor build).  gfx950 only.
+#pragma once
+#include "rtmi_host.hpp"
+
+#include <mutex>
+
+struct rtmi_patches {
+	rtmi_scene *scene;
+	uint32_t n;
+	double *d_verts;   // n × 9: v1, v2, v3 in ORIGINAL order (util.cpp:113-115 samples from these)
+	double *d_normals; // n × 3: triNormal
+	double *d_area;    // n: vec3.h:116-118
+	uint32_t *d_noninv; // elements whose pseudo-inverse does not exist: inside for every point of their plane (util.cpp:146)
+	uint32_t n_noninv;
+	double *d_display; // n × 16 (display path): triNormal, triVert1, pseudo-inverse rows A, B (mat3x2.h:187-283), (−n)·v1, invertible, pad
+	uint64_t verts_hash; // of the vertex array (must be the one the scene was built from)
+	// tables of the form-factor kernel (rtmi_formfactor.hip), built on the first rtmi_form_factors_dev call
+	std::mutex ff_mutex;
+	bool ff_ready = false;
+	void *d_chain = nullptr;   // ChainEntry[]: per patch, the siblings along its root-to-leaf path
+	void *d_meta = nullptr;    // PatchMeta[n]
+	uint32_t *d_dfs = nullptr; // patch ids in depth-first leaf order, padded with RTMI_MISS to a multiple of 64
+	uint32_t n_groups = 0;     // 64-patch groups of d_dfs
+	uint64_t chain_entries = 0;
+};
+
+namespace rtmi {
+
+constexpr double kEpsilon = 1.0e-5;       // Render2/base.h:57
+constexpr double kPi = 3.14159265358979;  // Render2/base.h:52
+constexpr uint32_t kLightStream = 0xFFFFFFFFu;
+
+struct rtmi_patches_dev_view { // what the display kernels read
+	const double *verts, *normals, *display;
+	uint32_t n;
+	const uint32_t *noninv;
+	uint32_t n_noninv;
+};
+
+struct PatchesDev {
+	const double *verts, *normals, *area;
+	uint32_t n;
+};
+
+// ---- counter-based sample generator (documented in DESIGN.md; the oracle restates it) ----------------
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+	z += 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+// uniform point on patch e for stream (seed, a, b, k, which); barycentric mix as Render2/util.cpp:113-115
+// (h0 = mix64(seed ^ (a << 32 | b)) is the same for every sample of a pair: callers may hoist it)
+__device__ __forceinline__ D3 sample_point_h(const double *__restrict__ e, uint64_t h0, uint32_t k, uint32_t which) {
+	const uint64_t h = mix64(h0 ^ (((uint64_t)k << 32) | which));
+	double u = (double)(h >> 11) * 0x1.0p-53;
+	double v = (double)(mix64(h) >> 11) * 0x1.0p-53;
+	if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
+	const double w = 1.0 - u - v;
+	return d3((w * e[0]) + (u * e[3]) + (v * e[6]), (w * e[1]) + (u * e[4]) + (v * e[7]),
+	          (w * e[2]) + (u * e[5]) + (v * e[8]));
+}
+__device__ __forceinline__ D3 sample_point(const double *__restrict__ e, uint64_t seed, uint32_t a, uint32_t b,
+                                           uint32_t k, uint32_t which) {
+	return sample_point_h(e, mix64(seed ^ (((uint64_t)a << 32) | b)), k, which);
+}
+
+inline int check_patches(const rtmi_patches *p, const char *who) {
+	if (!p) return fail(std::string(who) + ": patches is NULL");
+	int dev = -1;
+	if (hipGetDevice(&dev) != hipSuccess || dev != p->scene->device)
+		return fail(std::string(who) + ": the patches live on another device than the current one");
+	return 0;
+}
+inline PatchesDev pdev(const rtmi_patches *p) {
+	PatchesDev d;
+	d.verts = p->d_verts; d.normals = p->d_normals; d.area = p->d_area; d.n = p->n;
+	return d;
+}
+
+// Render2/radiosity.cpp:231-262 (+ :202-229, object.cpp:23): is xj on patch j visible from xi?
+// dir = Unit(xj − xi) and org = xi + 1e-5·dir are the caller's (the form-factor kernel reuses them).
+__device__ __forceinline__ bool visible_along(const SceneDev &S, const PatchesDev &P, uint32_t j, D3 org, D3 dir, D3 yi, int *stack) {
+	HitP h;
+	trace<false, false, false>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h); // binary nodes, see node_step
+	if (h.pos == RTMI_MISS) return false;
+	// hit.point = o + (d·((v1 − o)·n)) / (n·d)   with the HIT triangle's first vertex and normal
+	const GTri &T = S.tris[h.pos];
+	const double *np = P.normals + 3 * (size_t)T.orig;
+	const D3 n = d3(np[0], np[1], np[2]);
+	const D3 v1 = d3(T.v0[0], T.v0[1], T.v0[2]);
+	const D3 p = org + (dot(v1 - org, n) * dir) / dot(n, dir);
+	const double *nj = P.normals + 3 * (size_t)j;
+	return sqrt(len2(p - yi)) < kEpsilon && dot(dir, d3(nj[0], nj[1], nj[2])) < 0;
+}
+__device__ __forceinline__ bool visible(const SceneDev &S, const PatchesDev &P, uint32_t j, D3 xi, D3 yi, int *stack) {
+	const D3 dir = unit(yi - xi);
+	return visible_along(S, P, j, xi + (kEpsilon * dir), dir, yi, stack);
+}
+
+} // namespace rtmi

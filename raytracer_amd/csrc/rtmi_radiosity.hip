@@ -3,7 +3,7 @@
 // Reference: Render2/radiosity.cpp.  Form factors are evaluated in double exactly as the reference
 // writes them (:305-333, :264-303) on sample points from a counter-based generator, then rounded
 // once to fp32 for storage; the solve streams that fp32 matrix from HBM once per sweep.
-#include "rtmi_host.hpp"
+#include "rtmi_rad_device.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -11,75 +11,7 @@
 #include <mutex>
 #include <vector>
 
-struct rtmi_patches {
-	rtmi_scene *scene;
-	uint32_t n;
-	double *d_verts;   // n × 9: v1, v2, v3 in ORIGINAL order (util.cpp:113-115 samples from these)
-	double *d_normals; // n × 3: triNormal
-	double *d_area;    // n: vec3.h:116-118
-	uint32_t *d_noninv; // elements whose pseudo-inverse does not exist: inside for every point of their plane (util.cpp:146)
-	uint32_t n_noninv;
-	double *d_display; // n × 16 (display path): triNormal, triVert1, pseudo-inverse rows A, B (mat3x2.h:187-283), (−n)·v1, invertible, pad
-};
-
 namespace rtmi {
-
-constexpr double kEpsilon = 1.0e-5;       // Render2/base.h:57
-constexpr double kPi = 3.14159265358979;  // Render2/base.h:52
-constexpr uint32_t kLightStream = 0xFFFFFFFFu;
-
-struct rtmi_patches_dev_view { // what the display kernels read
-	const double *verts, *normals, *display;
-	uint32_t n;
-	const uint32_t *noninv;
-	uint32_t n_noninv;
-};
-
-struct PatchesDev {
-	const double *verts, *normals, *area;
-	uint32_t n;
-};
-
-// ---- counter-based sample generator (documented in DESIGN.md; the oracle restates it) ----------------
-__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
-	z += 0x9E3779B97F4A7C15ull;
-	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-	return z ^ (z >> 31);
-}
-
-// uniform point on patch e for stream (seed, a, b, k, which); barycentric mix as Render2/util.cpp:113-115
-__device__ __forceinline__ D3 sample_point(const double *__restrict__ e, uint64_t seed, uint32_t a, uint32_t b,
-                                           uint32_t k, uint32_t which) {
-	uint64_t h = mix64(seed ^ (((uint64_t)a << 32) | b));
-	h = mix64(h ^ (((uint64_t)k << 32) | which));
-	double u = (double)(h >> 11) * 0x1.0p-53;
-	double v = (double)(mix64(h) >> 11) * 0x1.0p-53;
-	if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
-	const double w = 1.0 - u - v;
-	return d3((w * e[0]) + (u * e[3]) + (v * e[6]), (w * e[1]) + (u * e[4]) + (v * e[7]),
-	          (w * e[2]) + (u * e[5]) + (v * e[8]));
-}
-
-// Render2/radiosity.cpp:231-262 (+ :202-229, object.cpp:23): is xj on patch j visible from xi?
-// dir = Unit(xj − xi) and org = xi + 1e-5·dir are the caller's (the form-factor kernel reuses them).
-__device__ __forceinline__ bool visible_along(const SceneDev &S, const PatchesDev &P, uint32_t j, D3 org, D3 dir, D3 yi, int *stack) {
-	HitP h;
-	trace<false, false, false>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h); // binary nodes, see node_step
-	if (h.pos == RTMI_MISS) return false;
-	// hit.point = o + (d·((v1 − o)·n)) / (n·d)   with the HIT triangle's first vertex and normal
-	const GTri &T = S.tris[h.pos];
-	const double *np = P.normals + 3 * (size_t)T.orig;
-	const D3 n = d3(np[0], np[1], np[2]);
-	const D3 v1 = d3(T.v0[0], T.v0[1], T.v0[2]);
-	const D3 p = org + (dot(v1 - org, n) * dir) / dot(n, dir);
-	const double *nj = P.normals + 3 * (size_t)j;
-	return sqrt(len2(p - yi)) < kEpsilon && dot(dir, d3(nj[0], nj[1], nj[2])) < 0;
-}
-__device__ __forceinline__ bool visible(const SceneDev &S, const PatchesDev &P, uint32_t j, D3 xi, D3 yi, int *stack) {
-	const D3 dir = unit(yi - xi);
-	return visible_along(S, P, j, xi + (kEpsilon * dir), dir, yi, stack);
-}
 
 RTMI_TRAVERSAL_KERNEL void k_visible_points(SceneDev S, PatchesDev P, uint64_t m,
                                                            const int32_t *__restrict__ ej, const double *__restrict__ xi,
@@ -89,75 +21,6 @@ RTMI_TRAVERSAL_KERNEL void k_visible_points(SceneDev S, PatchesDev P, uint64_t m
 	if (k >= m) return;
 	const D3 a = d3(xi[3 * k], xi[3 * k + 1], xi[3 * k + 2]), b = d3(xj[3 * k], xj[3 * k + 1], xj[3 * k + 2]);
 	vis[k] = visible(S, P, (uint32_t)ej[k], a, b, stack + threadIdx.x) ? 1 : 0;
-}
-
-// One lane per matrix entry (i, j): j runs fastest so a wave writes 256 contiguous bytes of a row of F
-// and its 64 × S visibility rays leave the same patch i.
-//   j <  n_patches, i != j : Render2/radiosity.cpp:305-333 (findFormFactorTerm)
-//   j == n_patches (light) : Render2/radiosity.cpp:264-303 (findFormFactorTermWithLight)
-//   i == n_patches or i == j : 0   (:382, :391-393)
-#ifndef RTMI_FF_WAVES
-#define RTMI_FF_WAVES 7
-#endif
-RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDev P, bool has_light, double cx, double cy,
-                                                         double cz, uint32_t samples, uint32_t light_samples,
-                                                         uint64_t seed, uint32_t flags, uint32_t row0, uint32_t n_rows,
-                                                         uint32_t n, float *__restrict__ F, uint64_t ld) {
-	extern __shared__ int stack_all[]; // rtmi_scene::stack_bytes_binary
-	int *stack = stack_all + threadIdx.x;
-	const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-	if (idx >= (uint64_t)n_rows * n) return;
-	const uint32_t r = (uint32_t)(idx / n), j = (uint32_t)(idx % n), i = row0 + r;
-	double out = 0.0;
-	if (i < P.n && j < P.n && i != j) {
-		const double *ei = P.verts + 9 * (size_t)i, *ejp = P.verts + 9 * (size_t)j;
-		const D3 ni = d3(P.normals[3 * (size_t)i], P.normals[3 * (size_t)i + 1], P.normals[3 * (size_t)i + 2]);
-		const D3 nj = d3(P.normals[3 * (size_t)j], P.normals[3 * (size_t)j + 1], P.normals[3 * (size_t)j + 2]);
-		const double area_j = P.area[j];
-		const double area_term = area_j / (int)samples; // :319, the same for every sample
-		double ff = 0.0;
-		for (uint32_t k = 0; k < samples; ++k) {
-			const D3 xi = sample_point(ei, seed, i, j, k, 0), xj = sample_point(ejp, seed, i, j, k, 1);
-			// Unit(xj − xi) once: the reference evaluates it three times (:235, :317, and Unit(xi − xj) = its exact
-			// negation, :318), and dist2 = (xi−xj)·(xi−xj) is the squared length inside it — same IEEE operations.
-			const D3 vec = xj - xi;
-			const double dist2 = len2(vec);
-			const D3 dir = dist2 > 0.0 ? vec / sqrt(dist2) : d3(0, 0, 0);
-			// A sample adds to the sum only if delF > 0, i.e. both cosines are positive (:320-324) — whatever the
-			// visibility ray says.  So the ray is shot only for those samples: back-facing and coplanar pairs
-			// (the grazing rays along a wall, the most expensive ones) cost nothing, and F is unchanged bit for bit.
-			const double c1 = dot(dir, ni);
-			const double c2 = -dot(dir, nj);
-			if (c1 > 0.0 && c2 > 0.0 && visible_along(S, P, j, xi + (kEpsilon * dir), dir, xj, stack)) {
-				const double cosFactor = c1 * c2;
-				const double delF = cosFactor / ((kPi * dist2) + area_term);
-				if (delF > 0.0) ff += delF;
-			}
-		}
-		ff = ff / ((double)samples);
-		out = ff * area_j;
-	} else if (has_light && i < P.n && j == P.n) {
-		const double *ei = P.verts + 9 * (size_t)i;
-		const D3 ni = d3(P.normals[3 * (size_t)i], P.normals[3 * (size_t)i + 1], P.normals[3 * (size_t)i + 2]);
-		const D3 C = d3(cx, cy, cz);
-		const bool mean = (flags & RTMI_FF_LIGHT_MEAN) != 0;
-		double ff = 0.0;
-		// the reference zeroes its accumulator inside the loop (:276): only the last sample survives
-		for (uint32_t k = mean ? 0u : light_samples - 1; k < light_samples; ++k) {
-			const D3 x = sample_point(ei, seed, i, kLightStream, k, 0);
-			const D3 dir = unit(C - x);
-			const D3 org = x + (kEpsilon * ni);
-			const double L = sqrt(len2(C - x));
-			const double tmp = ((1.0 / (4.0 * kPi)) * (dot(dir, ni) / (L * L)));
-			if (tmp > 0.0) { // only a positive term is ever added (:297-299): the ray is needed for those alone
-				HitP h;
-				trace<true, false, false>(S, org.x, org.y, org.z, dir.x, dir.y, dir.z, RTMI_INFINITY, stack, h);
-				if (h.pos == RTMI_MISS) ff += tmp;
-			}
-		}
-		out = light_samples ? ff / ((double)light_samples) : 0.0;
-	}
-	F[(uint64_t)r * ld + j] = (float)out;
 }
 
 // ---- Jacobi sweep: HBM-bound streaming of F -------------------------------------------------------------
@@ -567,20 +430,6 @@ static bool display_uses_bvh(const rtmi_patches *P) {
 	return force == 1 ? false : force == 2 ? true : P->n >= 256;
 }
 
-static int check_patches(const rtmi_patches *p, const char *who) {
-	if (!p) return fail(std::string(who) + ": patches is NULL");
-	int dev = -1;
-	if (hipGetDevice(&dev) != hipSuccess || dev != p->scene->device)
-		return fail(std::string(who) + ": the patches live on another device than the current one");
-	return 0;
-}
-
-static PatchesDev pdev(const rtmi_patches *p) {
-	PatchesDev d;
-	d.verts = p->d_verts; d.normals = p->d_normals; d.area = p->d_area; d.n = p->n;
-	return d;
-}
-
 // ---- the static scratch of rtmi_radiosity_solve_noalloc_dev -----------------------------------------------------------
 // Device memory that exists from the moment the code object is loaded: callers that must not allocate (HIP graph capture,
 // tight serving loops) get the solver's ping-pong vector and its norm windows from here.  Every GPU the library runs on
@@ -620,6 +469,8 @@ rtmi_patches *rtmi_patches_create(rtmi_scene *s, const double *verts, const doub
 	if (hipGetDevice(&dev) != hipSuccess || dev != s->device) { fail("rtmi_patches_create: wrong current device"); return nullptr; }
 	if (s->n_tris == 0 || s->n_tris > 0x7fffffffu) { fail("rtmi_patches_create: scene has no (or too many) triangles"); return nullptr; }
 	const uint32_t n = (uint32_t)s->n_tris;
+	// patch i IS triangle i of the scene: the form-factor kernel tests "triangle j" from these vertices
+	if (hash_doubles(verts, 9 * (uint64_t)n) != s->xyz_hash) { fail("rtmi_patches_create: verts is not the array the scene was built from"); return nullptr; }
 	// Area(v1,v2,v3) = Length((v2−v1)^(v3−v1)) / 2, Render2/vec3.h:116-118, same operation order (host IEEE double)
 	std::vector<double> area(n);
 	for (uint32_t i = 0; i < n; ++i) {
@@ -637,6 +488,7 @@ rtmi_patches *rtmi_patches_create(rtmi_scene *s, const double *verts, const doub
 	rtmi_patches *P = new rtmi_patches();
 	P->scene = s;
 	P->n = n;
+	P->verts_hash = s->xyz_hash;
 	P->d_verts = P->d_normals = P->d_area = P->d_display = nullptr;
 	P->d_noninv = nullptr;
 	P->n_noninv = (uint32_t)noninv.size();
@@ -665,6 +517,9 @@ void rtmi_patches_destroy(rtmi_patches *P) {
 	if (P->d_area) (void)hipFree(P->d_area);
 	if (P->d_display) (void)hipFree(P->d_display);
 	if (P->d_noninv) (void)hipFree(P->d_noninv);
+	if (P->d_chain) (void)hipFree(P->d_chain);
+	if (P->d_meta) (void)hipFree(P->d_meta);
+	if (P->d_dfs) (void)hipFree(P->d_dfs);
 	delete P;
 }
 
@@ -695,26 +550,6 @@ int rtmi_visible_points(rtmi_patches *P, uint64_t m, const int32_t *ej, const do
 	if (d_xj) (void)hipFree(d_xj);
 	if (d_vis) (void)hipFree(d_vis);
 	return rc;
-}
-
-int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t samples, uint32_t light_samples,
-                          uint64_t seed, uint32_t flags, uint32_t row0, uint32_t n_rows, float *d_F, uint64_t ld,
-                          void *stream) {
-	const char *who = "rtmi_form_factors_dev";
-	if (check_patches(P, who)) return -1;
-	const uint32_t n = P->n + (light_center ? 1u : 0u);
-	if (n_rows == 0) return 0;
-	if (!d_F) return fail(std::string(who) + ": d_F is NULL");
-	if (samples == 0) return fail(std::string(who) + ": samples must be >= 1");
-	if ((uint64_t)row0 + n_rows > n) return fail(std::string(who) + ": row range exceeds n");
-	if (ld < n) return fail(std::string(who) + ": ld < n");
-	const uint64_t total = (uint64_t)n_rows * n, grid = (total + kBlock - 1) / kBlock;
-	if (grid > 0x7fffffffull) return fail(std::string(who) + ": too many entries for one launch; shard the rows");
-	const double cx = light_center ? light_center[0] : 0.0, cy = light_center ? light_center[1] : 0.0,
-	             cz = light_center ? light_center[2] : 0.0;
-	hipLaunchKernelGGL(k_form_factors, dim3((uint32_t)grid), dim3(kBlock), P->scene->stack_bytes_binary, (hipStream_t)stream, P->scene->dev, pdev(P),
-	                   light_center != nullptr, cx, cy, cz, samples, light_samples, seed, flags, row0, n_rows, n, d_F, ld);
-	return launch_check(who);
 }
 
 // One sweep; the three norms are accumulated into `slots` triples (block b into triple b % slots), which the caller adds up.

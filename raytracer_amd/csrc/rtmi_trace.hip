@@ -323,6 +323,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	s->dev.nodes = nullptr; s->dev.wnodes = nullptr; s->dev.tris = nullptr; s->dev.root_ref = kSentinel; s->dev.absmax = 0.f;
 	for (int a = 0; a < 3; ++a) { s->dev.qlo[a] = 0.f; s->dev.qstep[a] = 0.f; }
 	s->d_v1_orig = nullptr;
+	s->xyz_hash = hash_doubles(xyz, 9 * n);
 	s->d_queue = nullptr;
 	s->next_slot = 0;
 	{

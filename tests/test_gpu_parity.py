@@ -197,6 +197,67 @@ def test_closed_box_form_factors_rows(rt, oracle):
         assert want.sum() > 0.3                                    # a closed box: most of the hemisphere is covered
 
 
+def _ff_scenes():
+    """(name, verts, normals): geometry that exercises every branch of the form-factor kernel's path walk — occluders
+    between the patches (studio, box in a box), random orientations and depths (soup), tiny scenes (1, 2, 3 patches),
+    rows across the 64-patch groups."""
+    from raytracer_amd import workloads
+    out = []
+    v, _, _, _ = workloads.studio(3)
+    out.append(("studio", v, workloads.face_normals(v)))
+    vb, nb, _ = workloads.closed_box(5, hole=0.4)
+    inner = workloads._box((3.0, 2.0, 0.0), (6.0, 5.5, 4.0), 2)
+    out.append(("box_in_box", np.concatenate([vb, inner]), np.concatenate([nb, workloads.face_normals(inner)])))
+    sp = workloads.soup(700, seed=3, edge=0.35)
+    out.append(("soup", sp, workloads.face_normals(sp)))
+    for m in (1, 2, 3):
+        out.append(("tiny%d" % m, sp[:m], workloads.face_normals(sp[:m])))
+    return out
+
+
+@pytest.mark.parametrize("name", ["studio", "box_in_box", "soup", "tiny1", "tiny2", "tiny3"])
+def test_form_factor_path_walk_equals_root_traversal_and_oracle(rt, oracle, monkeypatch, name):
+    """rtmi_form_factors_dev finds each ray's closest hit from the two patches' paths (rtmi_formfactor.hip); the round-1
+    kernel (RTMI_FF_KERNEL=flat) descends from the root.  Same F bit for bit, and both equal the oracle's rows."""
+    verts, normals = next((v, n) for nm, v, n in _ff_scenes() if nm == name)
+    n = len(verts)
+    scene = rt.Scene(verts)
+    rad = rt.Radiosity(scene, normals, None)
+    monkeypatch.delenv("RTMI_FF_KERNEL", raising=False)
+    F_path = rad.findFormFactor(samples=10, seed=11).cpu().numpy()[:, :n]
+    monkeypatch.setenv("RTMI_FF_KERNEL", "flat")
+    F_flat = rad.findFormFactor(samples=10, seed=11).cpu().numpy()[:, :n]
+    monkeypatch.delenv("RTMI_FF_KERNEL", raising=False)
+    assert np.array_equal(F_path.view(np.uint32), F_flat.view(np.uint32))
+    rows = sorted(set([0, n // 3, n - 1]))
+    for r in rows:
+        want = oracle.form_factors(verts, normals, 10, 11, row0=r, n_rows=1)[0].astype(np.float32)
+        assert np.array_equal(F_path[r], want)
+    if n > 100:
+        assert (F_path > 0).mean() > 0.02 and (F_path == 0).mean() > 0.2     # both visible and hidden / back-facing pairs
+    # a band that starts and ends inside 64-patch groups, with a band size that does not divide it
+    if n > 200:
+        monkeypatch.setenv("RTMI_FF_BAND", "7")
+        part = rad.findFormFactor(samples=10, seed=11, row0=61, n_rows=75).cpu().numpy()[:, :n]
+        monkeypatch.delenv("RTMI_FF_BAND", raising=False)
+        assert np.array_equal(part, F_path[61:136])
+
+
+def test_patches_must_be_the_scenes_triangles(rt):
+    from raytracer_amd import workloads
+    v = workloads.soup(50, seed=2, edge=0.3)
+    scene = rt.Scene(v)
+    other = v.copy()
+    other[7, 4] += 1e-9
+    with pytest.raises(rt.RtmiError, match="not the array the scene was built from"):
+        scene_tri = scene.tri_xyz
+        scene.tri_xyz = other
+        try:
+            rt.Radiosity(scene, workloads.face_normals(v), None)
+        finally:
+            scene.tri_xyz = scene_tri
+
+
 @pytest.mark.parametrize("n_tris,n_rays", [(1, 4096), (5, 4096), (3000, 60000)])
 def test_soup_closest_and_any_hit_vs_brute_force(rt, oracle, n_tris, n_rays):
     from raytracer_amd import workloads

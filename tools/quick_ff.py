@@ -18,6 +18,8 @@ F = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=1000, n_rows=r
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 dig = hashlib.sha1(F.cpu().numpy().tobytes()).hexdigest()[:12]
+if os.environ.get("DUMP"):
+    np.save(os.environ["DUMP"], F.cpu().numpy())
 i = box.info()
 print("box %d patches depth %d | %d rows %.4f s  %.1f M pair-samples/s  full build %.1f s  row sum %.4f digest %s %s" % (
     rad.numOfElements, i.max_depth, rows, dt, 10.0 * rows * (rad.n - 2) / dt / 1e6, dt * rad.n / rows, float(F[0].sum()), dig,
