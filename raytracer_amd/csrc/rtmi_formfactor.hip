@@ -48,6 +48,7 @@ struct __attribute__((aligned(16))) ChainEntry {
 struct __attribute__((aligned(16))) PatchMeta {
 	uint32_t chain_off, path, depth, leafpos;
 };
+constexpr uint32_t kBehind = 0x100u; // ChainEntry::level: the sibling lies wholly behind (or in) the plane of the path's own patch
 struct FFTables {
 	const ChainEntry *chain;
 	const PatchMeta *meta;
@@ -78,6 +79,36 @@ __device__ __forceinline__ bool slab_box(const float4 a, const float4 b, const R
 	return tn <= tf;
 }
 
+// Pair level: a sibling that is an inner node and whose box the beam meets is walked with the BEAM (at most kBeamBudget
+// node visits, on the lane's own stack): if the beam meets no leaf's box below it, no ray of the pair can hit anything
+// there, and the sibling is dropped for all samples of the pair.  This is what disposes of the big boxes at the top of a
+// room's hierarchy (pieces of several flat walls in one box = a hollow volume the rays cross).
+constexpr int kBeamBudget = 12;
+__device__ __forceinline__ bool beam_meets_leaf(const SceneDev &S, int ref, const RayS &beam, int *stack) {
+	if (ref < 0) return true; // a leaf: its box was the test
+	int sp = 0, cur = ref;
+	for (int visits = 0; visits < kBeamBudget; ++visits) {
+		const QNode *np = S.nodes + cur;
+		const uint4 a = np->a, b = np->b;
+		auto box = [&](uint32_t wx, uint32_t wy, uint32_t wz) {
+			const float4 lo = make_float4(fmaf((float)(wx & 0xffffu), S.qstep[0], S.qlo[0]), fmaf((float)(wy & 0xffffu), S.qstep[1], S.qlo[1]),
+			                              fmaf((float)(wz & 0xffffu), S.qstep[2], S.qlo[2]), 0.f);
+			const float4 hi = make_float4(fmaf((float)(wx >> 16), S.qstep[0], S.qlo[0]), fmaf((float)(wy >> 16), S.qstep[1], S.qlo[1]),
+			                              fmaf((float)(wz >> 16), S.qstep[2], S.qlo[2]), 0.f);
+			return slab_box(lo, hi, beam, 1.0f);
+		};
+		const bool h0 = box(a.x, a.y, a.z), h1 = box(a.w, b.x, b.y);
+		const int r0 = (int)b.z, r1 = (int)b.w;
+		if ((h0 && r0 < 0) || (h1 && r1 < 0)) return true;
+		if (h0 && h1) { stack[sp * kBlock] = r1; ++sp; cur = r0; }
+		else if (h0) cur = r0;
+		else if (h1) cur = r1;
+		else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+		else return false;
+	}
+	return true; // out of budget: keep the sibling
+}
+
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 #pragma unroll
@@ -105,6 +136,16 @@ __device__ __forceinline__ void patch_bounds(const double *v, float lo[3], float
 	}
 }
 
+// Work counters of the form-factor kernel (diagnostic builds only: make EXTRA=-DRTMI_FF_COUNT; tools/ff_counts.py)
+#ifdef RTMI_FF_COUNT
+__device__ unsigned long long g_ff_counts[16];
+#define FF_COUNT(k, n) do { if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&g_ff_counts[k], (unsigned long long)(n)); } while (0)
+#define FF_COUNT_LANES(k, pred) FF_COUNT(k, __popcll(__ballot(pred)))
+#else
+#define FF_COUNT(k, n) do { } while (0)
+#define FF_COUNT_LANES(k, pred) do { } while (0)
+#endif
+
 // The ordinary stack traversal (binary nodes), started from whatever a lane holds: `cur` (a node, a leaf reference, or
 // kSentinel) and `sp` entries on its stack.  Closest hit with the tie rule; vote-scheduled like trace(): per iteration the
 // wave takes ONE node step or ONE triangle step.
@@ -122,8 +163,10 @@ __device__ __forceinline__ void trace_from(const SceneDev &S, const RayF &rf, do
 		const int n_node = __popcll(__ballot(cur >= 0)), n_leaf = __popcll(__ballot(cur == kLeaf));
 		if (n_node + n_leaf == 0) break;
 		if (n_node >= n_leaf) {
+			FF_COUNT(6, 1); FF_COUNT(11, n_node);
 			if (cur >= 0) cur = node_step(S, rf, tbest, cur, sp, stack);
 		} else if (cur == kLeaf) {
+			FF_COUNT(7, 1); FF_COUNT(12, n_leaf);
 			const GTri T = load_tri(S.tris + tk);
 			double u = 0.0, v = 0.0;
 			const double t = mt_exact(ox, oy, oz, dx, dy, dz, T, u, v);
@@ -184,9 +227,15 @@ RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx
 // per-lane tables are fetched once per workgroup and shared through the L1.  Columns j < n_patches only; the light's row
 // (i == n_patches) is zero (:391-393), the diagonal too (:382).
 // stack: 2·(depth + 1) entries per lane — up to depth + 1 sibling subtrees waiting, and the traversal inside one of them.
-RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDev P, FFTables T, uint32_t samples, uint64_t seed,
-                                                           uint32_t row0, uint32_t n_rows, uint32_t band_rows, float margin,
-                                                           uint32_t pend_cap, float *__restrict__ F, uint64_t ld) {
+// (The tables come as separate __restrict__ pointers: only then does the compiler know that the stores to F cannot change
+// them, and fetches everything that depends on i alone with scalar loads.)
+RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const double *__restrict__ p_verts, const double *__restrict__ p_normals,
+                                                           const double *__restrict__ p_area, uint32_t p_n, const ChainEntry *__restrict__ t_chain,
+                                                           const PatchMeta *__restrict__ t_meta, const uint32_t *__restrict__ t_dfs,
+                                                           uint32_t samples, uint64_t seed, uint32_t row0, uint32_t n_rows, uint32_t band_rows,
+                                                           float margin, uint32_t pend_cap, float *__restrict__ F, uint64_t ld) {
+	struct { const double *verts, *normals, *area; uint32_t n; } P = {p_verts, p_normals, p_area, p_n};
+	struct { const ChainEntry *chain; const PatchMeta *meta; const uint32_t *dfs; } T = {t_chain, t_meta, t_dfs};
 	extern __shared__ int stack_all[];
 	int *stack = stack_all + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u;
@@ -227,7 +276,11 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDe
 			// rounding of patch j's bounds; such a segment stays within max(half extents) of the line between the two
 			// boxes' centres.  `margin` covers the 1e-5, the per-ray pad of the exact test and all fp32 roundings.
 			// mask_i / mask_j: bit L = the sibling at level L of path i / path j may be met by a ray of this pair.
-			uint32_t mask_i = 0u, mask_j = 0u;
+			// *_front: without the siblings that lie wholly behind (or in) the patch's own plane — flagged on the host, in
+			// double, from exact bounds (build_ff_tables).  A ray that leaves patch i with cos > 1e-3 rises above that plane
+			// at once, so it meets such triangles only at t <= −1e-5/2 < 0; one that arrives on j with cos > 1e-3 meets them
+			// no earlier than 2.5e-6 before its hit on j, where every hit gives the same verdict as the hit on j itself.
+			uint32_t mask_i = 0u, mask_j = 0u, front_i = 0u, front_j = 0u;
 			const uint32_t xij = mi.path ^ mj.path, xi0 = mi.path ^ m0.path;
 			const uint32_t lca = (pair && xij) ? (uint32_t)(__ffs((int)xij) - 1) : 0u;     // first level where the paths part
 			const uint32_t lca0 = xi0 ? (uint32_t)(__ffs((int)xi0) - 1) : 32u;              // ... for the group's first patch (uniform)
@@ -242,24 +295,34 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDe
 				const RayS beam = make_rays(cax, cay, caz, cbx - cax, cby - cay, cbz - caz, px, py, pz);
 				for (uint32_t L = 0; L < mi.depth; ++L) { // wave-uniform entries
 					const float4 a = *reinterpret_cast<const float4 *>(chain_i + L), b = *(reinterpret_cast<const float4 *>(chain_i + L) + 1);
-					if (pair && L != lca && slab_box(a, b, beam, 1.0f)) mask_i |= 1u << L;
+					if (pair && L != lca && slab_box(a, b, beam, 1.0f) && beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) {
+						mask_i |= 1u << L;
+						if (!(__float_as_uint(b.w) & kBehind)) front_i |= 1u << L;
+					}
 				}
 				// path j above the group's common depth: if path i parts from the group there (lca0 < common), every lane's
 				// lca is lca0 and the levels between are the group's shared siblings
 				for (uint32_t L = lca0 + 1u; L < common; ++L) { // wave-uniform entries (empty when lca0 >= common)
 					const float4 a = *reinterpret_cast<const float4 *>(chain_0 + L), b = *(reinterpret_cast<const float4 *>(chain_0 + L) + 1);
-					if (pair && slab_box(a, b, beam, 1.0f)) mask_j |= 1u << L;
+					if (pair && slab_box(a, b, beam, 1.0f) && beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) {
+						mask_j |= 1u << L;
+						if (!(__float_as_uint(b.w) & kBehind)) front_j |= 1u << L;
+					}
 				}
 				for (uint32_t L = common; L < max_dj; ++L) { // per-lane entries
+					FF_COUNT(10, 1);
 					if (pair && L > lca && L < mj.depth) {
 						const float4 a = *reinterpret_cast<const float4 *>(chain_j + L), b = *(reinterpret_cast<const float4 *>(chain_j + L) + 1);
-						if (slab_box(a, b, beam, 1.0f)) mask_j |= 1u << L;
+						if (slab_box(a, b, beam, 1.0f) && beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) {
+							mask_j |= 1u << L;
+							if (!(__float_as_uint(b.w) & kBehind)) front_j |= 1u << L;
+						}
 					}
 				}
 			}
 			const uint32_t low = common >= 32u ? ~0u : ((1u << common) - 1u);
-			const uint32_t um_i = wave_or_u32(mask_i), um_j = wave_or_u32(mask_j & low);
-			const uint32_t own_j = mask_j & ~low;
+			const uint32_t um_i_all = wave_or_u32(mask_i), um_j_all = wave_or_u32(mask_j & low);
+			const uint32_t um_i_front = wave_or_u32(front_i), um_j_front = wave_or_u32(front_j & low);
 			// ---- the samples of the pair, in the reference's order (:309-330) --------------------------------------
 			const uint64_t h0 = mix64(seed ^ (((uint64_t)i << 32) | jj));
 			double ff = 0.0;
@@ -282,7 +345,9 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDe
 					org = xi + (kEpsilon * dir);
 					shoot = c1 > 0.0 && c2 > 0.0;
 				}
+				FF_COUNT(0, 1);
 				if (__ballot(shoot) == 0ull) continue;
+				FF_COUNT(13, 1); FF_COUNT_LANES(9, shoot);
 				double best = RTMI_INFINITY;
 				uint32_t pos = RTMI_MISS;
 				int cur = kSentinel, sp = 0;
@@ -310,29 +375,39 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, PatchesDe
 					else from_root = true;
 				};
 				// Triangle i lies 1e-5 BEHIND the origin along the ray (t = −1e-5 up to rounding of relative size 1e-15/c1): it
-				// cannot be hit unless the ray all but grazes it — then it is tested like any other.
-				if (walk && (!(c1 > 1e-3) || S.absmax > 1e4f)) push((int)~(mi.leafpos << 3));
+				// cannot be hit unless the ray all but grazes it — then it is tested like any other, and so is everything
+				// behind the two planes.
+				const bool graze_i = !(c1 > 1e-3), graze_j = !(c2 > 1e-3);
+				if (walk && (graze_i || S.absmax > 1e4f)) push((int)~(mi.leafpos << 3));
+				const uint32_t s_i = graze_i ? mask_i : front_i, s_j = graze_j ? mask_j : front_j;
+				const uint32_t um_i = __ballot(walk && graze_i) ? um_i_all : um_i_front, um_j = __ballot(walk && graze_j) ? um_j_all : um_j_front;
+				const uint32_t own_j = s_j & ~low;
 				// the siblings the beam met, against THIS ray (exact slab test, bounded by the hit on j)
 				for (uint32_t m = um_i; m; m &= m - 1u) { // wave-uniform
+					FF_COUNT(1, 1);
 					const uint32_t L = (uint32_t)__builtin_ctz(m);
 					const float4 a = *reinterpret_cast<const float4 *>(chain_i + L), b = *(reinterpret_cast<const float4 *>(chain_i + L) + 1);
-					if (walk && ((mask_i >> L) & 1u) && slab_box(a, b, rs, tb0)) push(__float_as_int(a.w));
+					if (walk && ((s_i >> L) & 1u) && slab_box(a, b, rs, tb0)) push(__float_as_int(a.w));
 				}
 				for (uint32_t m = um_j; m; m &= m - 1u) { // wave-uniform
+					FF_COUNT(2, 1);
 					const uint32_t L = (uint32_t)__builtin_ctz(m);
 					const float4 a = *reinterpret_cast<const float4 *>(chain_0 + L), b = *(reinterpret_cast<const float4 *>(chain_0 + L) + 1);
-					if (walk && ((mask_j >> L) & 1u) && slab_box(a, b, rs, tb0)) push(__float_as_int(a.w));
+					if (walk && ((s_j >> L) & 1u) && slab_box(a, b, rs, tb0)) push(__float_as_int(a.w));
 				}
 				for (uint32_t m = walk ? own_j : 0u; __ballot(m != 0u) != 0ull; m &= m - 1u) { // per lane
+					FF_COUNT(3, 1);
 					if (m) {
 						const uint32_t L = (uint32_t)__builtin_ctz(m);
 						const float4 a = *reinterpret_cast<const float4 *>(chain_j + L), b = *(reinterpret_cast<const float4 *>(chain_j + L) + 1);
 						if (slab_box(a, b, rs, tb0)) push(__float_as_int(a.w));
 					}
 				}
+				FF_COUNT_LANES(8, from_root); FF_COUNT(4, __popcll(__ballot(sp > 0))); FF_COUNT(14, __popcll(__ballot(sp > 1))); FF_COUNT(15, __popcll(__ballot(sp > 2)));
 				if (from_root) { best = RTMI_INFINITY; pos = RTMI_MISS; sp = 0; cur = S.root_ref; }
 				else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
 				if (__ballot(cur != kSentinel) != 0ull) {
+					FF_COUNT(5, 1);
 					const RayF rf = make_rayf(S, org.x, org.y, org.z, dir.x, dir.y, dir.z);
 					trace_from(S, rf, org.x, org.y, org.z, dir.x, dir.y, dir.z, best, pos, cur, sp, stack);
 				}
@@ -399,8 +474,13 @@ static float f32_below(double x) { float f = (float)x; return (double)f > x ? st
 static float f32_above_h(double x) { float f = (float)x; return (double)f < x ? std::nextafterf(f, INFINITY) : f; }
 
 // Walks the binary hierarchy as the device holds it and writes, per patch, the siblings along its path.
+struct Box3 { double lo[3], hi[3]; };
 struct TableWalk {
 	const rtmi_scene *s;
+	const double *verts = nullptr, *normals = nullptr; // host copies, original order
+	bool flags_on = false;  // the caller's normals are the triangles' geometric normals and the scene is small enough in coordinates
+	double delta = 0.0;
+	std::vector<Box3> sib_box; // exact (double) bounds of sib[L]'s subtree
 	std::vector<QNode> nodes;
 	std::vector<GTri> tris;
 	std::vector<ChainEntry> chain, sib; // sib[L] = the sibling at level L of the path being walked
@@ -409,6 +489,34 @@ struct TableWalk {
 	std::vector<uint8_t> seen;
 	bool bad = false;
 	double plane(uint32_t q, int a) const { return (double)s->dev.qlo[a] + (double)q * (double)s->dev.qstep[a]; }
+	// exact bounds of every subtree, bottom-up (index: inner node id; leaves are looked up directly)
+	std::vector<Box3> node_box;
+	Box3 leaf_box(int32_t ref) const {
+		const uint32_t id = tris[(~(uint32_t)ref) >> 3].orig;
+		const double *v = verts + 9 * (size_t)id;
+		Box3 b;
+		for (int a = 0; a < 3; ++a) {
+			b.lo[a] = std::min(v[a], std::min(v[3 + a], v[6 + a]));
+			b.hi[a] = std::max(v[a], std::max(v[3 + a], v[6 + a]));
+		}
+		return b;
+	}
+	Box3 bounds(int32_t ref, uint32_t depth) {
+		if (bad) return Box3();
+		if (ref < 0) {
+			const uint32_t code = ~(uint32_t)ref, pos = code >> 3;
+			if ((code & 7u) != 0u || pos >= tris.size() || tris[pos].orig >= meta.size()) { bad = true; return Box3(); }
+			return leaf_box(ref);
+		}
+		if ((size_t)ref >= nodes.size() || depth >= 31u) { bad = true; return Box3(); }
+		const QNode &q = nodes[ref];
+		const Box3 l = bounds((int32_t)q.b.z, depth + 1u), r = bounds((int32_t)q.b.w, depth + 1u);
+		Box3 b;
+		for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(l.lo[a], r.lo[a]); b.hi[a] = std::max(l.hi[a], r.hi[a]); }
+		node_box[ref] = b;
+		return b;
+	}
+	Box3 box_of(int32_t ref) const { return ref < 0 ? leaf_box(ref) : node_box[ref]; }
 	void walk(int32_t ref, uint32_t path, uint32_t depth) {
 		if (bad) return;
 		if (ref < 0) { // a leaf: ONE triangle (rtmi_scene_create builds leaves of one)
@@ -421,7 +529,18 @@ struct TableWalk {
 			meta[id].path = path;
 			meta[id].depth = depth;
 			meta[id].leafpos = pos;
+			const size_t at = chain.size();
 			chain.insert(chain.end(), sib.begin(), sib.end());
+			if (flags_on) { // which siblings lie wholly behind (or in) this patch's plane: support of their exact bounds along the normal
+				const double *v1 = verts + 9 * (size_t)id, *nr = normals + 3 * (size_t)id;
+				if (normal_is_geometric(id))
+					for (uint32_t L = 0; L < depth; ++L) {
+						const Box3 &b = sib_box[L];
+						double sup = 0.0;
+						for (int a = 0; a < 3; ++a) sup += std::max(nr[a] * (b.lo[a] - v1[a]), nr[a] * (b.hi[a] - v1[a]));
+						if (sup <= delta) chain[at + L].level |= kBehind;
+					}
+			}
 			dfs.push_back(id);
 			return;
 		}
@@ -439,10 +558,37 @@ struct TableWalk {
 			e[c].level = depth;
 		}
 		sib.push_back(e[1]); // walking into child 0, the other child is the sibling at this level
+		sib_box.push_back(flags_on ? box_of(child[1]) : Box3());
 		walk(child[0], path, depth + 1u);
 		sib.back() = e[0];
+		sib_box.back() = flags_on ? box_of(child[0]) : Box3();
 		walk(child[1], path | (1u << depth), depth + 1u);
 		sib.pop_back();
+		sib_box.pop_back();
+	}
+	// the caller's normal of patch id equals ± Unit((v2 − v1) ^ (v3 − v1)) to 1e-9 per component
+	bool normal_is_geometric(uint32_t id) const {
+		const double *v = verts + 9 * (size_t)id, *nr = normals + 3 * (size_t)id;
+		const double ax = v[3] - v[0], ay = v[4] - v[1], az = v[5] - v[2], bx = v[6] - v[0], by = v[7] - v[1], bz = v[8] - v[2];
+		double g[3] = {ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx};
+		const double len = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+		if (!(len > 0.0)) return false;
+		double dp = 0.0, dm = 0.0;
+		for (int a = 0; a < 3; ++a) {
+			dp = std::max(dp, std::fabs(nr[a] - g[a] / len));
+			dm = std::max(dm, std::fabs(nr[a] + g[a] / len));
+		}
+		return std::min(dp, dm) <= 1e-9;
+	}
+	// Degenerate patches (zero area) are never hit (|det| < 1e-8): they need no normal.
+	bool all_normals_geometric() const {
+		for (uint32_t id = 0; id < (uint32_t)meta.size(); ++id) {
+			const double *v = verts + 9 * (size_t)id;
+			const double ax = v[3] - v[0], ay = v[4] - v[1], az = v[5] - v[2], bx = v[6] - v[0], by = v[7] - v[1], bz = v[8] - v[2];
+			const double gx = ay * bz - az * by, gy = az * bx - ax * bz, gz = ax * by - ay * bx;
+			if (gx * gx + gy * gy + gz * gz > 0.0 && !normal_is_geometric(id)) return false;
+		}
+		return true;
 	}
 };
 
@@ -460,6 +606,19 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	if ((!W.nodes.empty() && hipMemcpy(W.nodes.data(), s->dev.nodes, W.nodes.size() * sizeof(QNode), hipMemcpyDeviceToHost) != hipSuccess) ||
 	    hipMemcpy(W.tris.data(), s->dev.tris, (size_t)n * sizeof(GTri), hipMemcpyDeviceToHost) != hipSuccess)
 		return fail(std::string(who) + ": reading the hierarchy back failed");
+	std::vector<double> h_verts(9 * (size_t)n), h_normals(3 * (size_t)n);
+	if (hipMemcpy(h_verts.data(), P->d_verts, h_verts.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+	    hipMemcpy(h_normals.data(), P->d_normals, h_normals.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+		return fail(std::string(who) + ": reading the patches back failed");
+	W.verts = h_verts.data();
+	W.normals = h_normals.data();
+	// "behind its patch's plane" flags: only when the p formula of ANY triangle that might win a tie is the true plane
+	// intersection (geometric normals throughout), and while 2·delta/1e-5 stays far below the kernel's cos threshold of 1e-3
+	W.delta = 9.094947017729282e-13 * (1.0 + (double)s->dev.absmax); // 2^-40·(1 + |coord|max)
+	const char *planes = std::getenv("RTMI_FF_PLANES"); // "0": no plane flags (tests compare both settings)
+	W.flags_on = W.delta <= 1.25e-9 && !(planes && planes[0] == '0') && W.all_normals_geometric();
+	W.node_box.resize(W.nodes.size());
+	if (W.flags_on) (void)W.bounds(s->dev.root_ref, 0u);
 	W.dfs.reserve(((size_t)n + 63) / 64 * 64);
 	W.walk(s->dev.root_ref, 0u, 0u);
 	if (W.bad || W.dfs.size() != n) return fail(std::string(who) + ": the hierarchy is not a binary tree over the patches with one triangle per leaf");
@@ -523,8 +682,8 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		const dim3 grid(P->n_groups, (n_bands + kBlock / 64 - 1) / (kBlock / 64));
 		const uint32_t pend_cap = s->info.max_depth + 1u; // siblings that may wait on a lane's stack; as many entries again serve the traversal
 		const uint32_t lds = 2u * (s->info.max_depth + 1u) * kBlock * (uint32_t)sizeof(int);
-		hipLaunchKernelGGL(k_form_factors, grid, dim3(kBlock), lds, st, s->dev, pdev(P), T, samples, seed, row0, n_rows, band, margin, pend_cap,
-		                   d_F, ld);
+		hipLaunchKernelGGL(k_form_factors, grid, dim3(kBlock), lds, st, s->dev, (const double *)P->d_verts, (const double *)P->d_normals,
+		                   (const double *)P->d_area, P->n, T.chain, T.meta, T.dfs, samples, seed, row0, n_rows, band, margin, pend_cap, d_F, ld);
 	}
 	if (launch_check(who)) return -1;
 	if (light_center) {
@@ -534,5 +693,15 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 	}
 	return 0;
 }
+
+#ifdef RTMI_FF_COUNT
+// diagnostic builds: reads and clears the work counters
+int rtmi_debug_ff_counts(uint64_t out[16]) {
+	unsigned long long z[16] = {0};
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ff_counts), sizeof z) != hipSuccess) return fail("rtmi_debug_ff_counts: copy failed");
+	if (hipMemcpyToSymbol(HIP_SYMBOL(g_ff_counts), z, sizeof z) != hipSuccess) return fail("rtmi_debug_ff_counts: clear failed");
+	return 0;
+}
+#endif
 
 } // extern "C"

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Work counters of the form-factor kernel on the closed box (diagnostic build: make -C raytracer_amd/csrc count)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["RTMI_LIB"] = os.path.join(ROOT, "raytracer_amd", "librtmi_count.so")
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import raytracer_amd as rt
+from raytracer_amd import workloads
+torch.cuda.set_device(0)
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 74
+verts, normals, light = workloads.closed_box(k)
+box = rt.Scene(verts)
+rad = rad = rt.Radiosity(box, normals, None)
+out = (C.c_uint64 * 16)()
+rad.findFormFactor(samples=10, seed=1, row0=1000, n_rows=rows)
+torch.cuda.synchronize()
+rt.lib.rtmi_debug_ff_counts(out)
+c = list(out)
+names = ["sample iterations (wave)", "um_i loop iterations", "um_j loop iterations", "own_j loop iterations", "lanes with >=1 sibling hit", "trace_from calls (wave)",
+         "node steps (wave)", "leaf steps (wave)", "from_root lanes", "shoot lanes", "prepass own-level iterations", "node-step lanes", "leaf-step lanes",
+         "sample iterations with a ray", "lanes with >=2", "lanes with >=3"]
+it = max(1, c[13])
+for n, v in zip(names, c):
+    print("%-32s %14d   per ray-iteration %.3f" % (n, v, v / it))
