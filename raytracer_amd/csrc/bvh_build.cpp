@@ -90,7 +90,33 @@ struct Builder {
 			return;
 		}
 		uint32_t mid = first;
-		{
+		// Wall peeling.  Triangles that lie IN one of the node's six boundary planes (a room's floor, a table top, the ground
+		// under a scene) are split off as a flat child when they are a sizeable part of the node.  The area heuristic below
+		// never does that — it prices a half-room (pieces of five walls in one hollow box) below "one wall | the rest" —
+		// yet rays that cross a room's interior then meet hollow box after hollow box; with the walls peeled the top of the
+		// hierarchy is six flat boxes a crossing ray misses at once (form factors: DESIGN.md §4, the pair-level beam test).
+		if (count >= 64) {
+			uint32_t in_plane[6] = {0, 0, 0, 0, 0, 0};
+			for (uint32_t i = first; i < first + count; ++i) {
+				const TriBox &t = tb[order[i]];
+				for (int a = 0; a < 3; ++a) {
+					if (t.lo[a] != t.hi[a]) continue;
+					if (t.lo[a] == b.lo[a]) ++in_plane[2 * a];
+					else if (t.lo[a] == b.hi[a]) ++in_plane[2 * a + 1];
+				}
+			}
+			int pick = -1;
+			for (int k = 0; k < 6; ++k)
+				if (in_plane[k] < count && in_plane[k] * 8u >= count && (pick < 0 || in_plane[k] > in_plane[pick])) pick = k;
+			if (pick >= 0) {
+				const int a = pick >> 1;
+				const float plane = (pick & 1) ? b.hi[a] : b.lo[a];
+				auto it = std::partition(order.begin() + first, order.begin() + first + count,
+				                         [&](uint32_t id2) { return tb[id2].lo[a] == plane && tb[id2].hi[a] == plane; });
+				mid = (uint32_t)(it - order.begin());
+			}
+		}
+		if (mid == first) {
 			int best_axis = -1, best_split = -1;
 			float best_cost = std::numeric_limits<float>::max();
 			for (int a = 0; a < 3; ++a) {

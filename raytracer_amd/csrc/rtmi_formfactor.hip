@@ -79,15 +79,29 @@ __device__ __forceinline__ bool slab_box(const float4 a, const float4 b, const R
 	return tn <= tf;
 }
 
+// Work counters of the form-factor kernel (diagnostic builds only: make EXTRA=-DRTMI_FF_COUNT; tools/ff_counts.py)
+#ifdef RTMI_FF_COUNT
+__device__ unsigned long long g_ff_counts[96];
+#define FF_COUNT(k, n) do { if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&g_ff_counts[k], (unsigned long long)(n)); } while (0)
+#define FF_COUNT_LANES(k, pred) FF_COUNT(k, __popcll(__ballot(pred)))
+#else
+#define FF_COUNT(k, n) do { } while (0)
+#define FF_COUNT_LANES(k, pred) do { } while (0)
+#endif
+
 // Pair level: a sibling that is an inner node and whose box the beam meets is walked with the BEAM (at most kBeamBudget
 // node visits, on the lane's own stack): if the beam meets no leaf's box below it, no ray of the pair can hit anything
 // there, and the sibling is dropped for all samples of the pair.  This is what disposes of the big boxes at the top of a
 // room's hierarchy (pieces of several flat walls in one box = a hollow volume the rays cross).
-constexpr int kBeamBudget = 12;
+#ifndef RTMI_FF_BEAM_BUDGET
+#define RTMI_FF_BEAM_BUDGET 12
+#endif
+constexpr int kBeamBudget = RTMI_FF_BEAM_BUDGET;
 __device__ __forceinline__ bool beam_meets_leaf(const SceneDev &S, int ref, const RayS &beam, int *stack) {
 	if (ref < 0) return true; // a leaf: its box was the test
 	int sp = 0, cur = ref;
 	for (int visits = 0; visits < kBeamBudget; ++visits) {
+		FF_COUNT(80, 1);
 		const QNode *np = S.nodes + cur;
 		const uint4 a = np->a, b = np->b;
 		auto box = [&](uint32_t wx, uint32_t wy, uint32_t wz) {
@@ -135,16 +149,6 @@ __device__ __forceinline__ void patch_bounds(const double *v, float lo[3], float
 		hi[a] = fmaxf(p, fmaxf(q, r));
 	}
 }
-
-// Work counters of the form-factor kernel (diagnostic builds only: make EXTRA=-DRTMI_FF_COUNT; tools/ff_counts.py)
-#ifdef RTMI_FF_COUNT
-__device__ unsigned long long g_ff_counts[16];
-#define FF_COUNT(k, n) do { if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&g_ff_counts[k], (unsigned long long)(n)); } while (0)
-#define FF_COUNT_LANES(k, pred) FF_COUNT(k, __popcll(__ballot(pred)))
-#else
-#define FF_COUNT(k, n) do { } while (0)
-#define FF_COUNT_LANES(k, pred) do { } while (0)
-#endif
 
 // The ordinary stack traversal (binary nodes), started from whatever a lane holds: `cur` (a node, a leaf reference, or
 // kSentinel) and `sp` entries on its stack.  Closest hit with the tie rule; vote-scheduled like trace(): per iteration the
@@ -294,28 +298,30 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				const float pz = fmaxf(ahi[2] - alo[2], bhi[2] - blo[2]) * 0.5f + margin;
 				const RayS beam = make_rays(cax, cay, caz, cbx - cax, cby - cay, cbz - caz, px, py, pz);
 				for (uint32_t L = 0; L < mi.depth; ++L) { // wave-uniform entries
+					FF_COUNT(81, 1);
 					const float4 a = *reinterpret_cast<const float4 *>(chain_i + L), b = *(reinterpret_cast<const float4 *>(chain_i + L) + 1);
-					if (pair && L != lca && slab_box(a, b, beam, 1.0f) && beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) {
-						mask_i |= 1u << L;
-						if (!(__float_as_uint(b.w) & kBehind)) front_i |= 1u << L;
+					if (pair && L != lca && slab_box(a, b, beam, 1.0f)) { // (a sibling behind the plane is not walked: only grazing rays need it)
+						if (__float_as_uint(b.w) & kBehind) mask_i |= 1u << L;
+						else if (beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) { mask_i |= 1u << L; front_i |= 1u << L; }
 					}
 				}
 				// path j above the group's common depth: if path i parts from the group there (lca0 < common), every lane's
 				// lca is lca0 and the levels between are the group's shared siblings
 				for (uint32_t L = lca0 + 1u; L < common; ++L) { // wave-uniform entries (empty when lca0 >= common)
+					FF_COUNT(82, 1);
 					const float4 a = *reinterpret_cast<const float4 *>(chain_0 + L), b = *(reinterpret_cast<const float4 *>(chain_0 + L) + 1);
-					if (pair && slab_box(a, b, beam, 1.0f) && beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) {
-						mask_j |= 1u << L;
-						if (!(__float_as_uint(b.w) & kBehind)) front_j |= 1u << L;
+					if (pair && slab_box(a, b, beam, 1.0f)) {
+						if (__float_as_uint(b.w) & kBehind) mask_j |= 1u << L;
+						else if (beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) { mask_j |= 1u << L; front_j |= 1u << L; }
 					}
 				}
 				for (uint32_t L = common; L < max_dj; ++L) { // per-lane entries
 					FF_COUNT(10, 1);
 					if (pair && L > lca && L < mj.depth) {
 						const float4 a = *reinterpret_cast<const float4 *>(chain_j + L), b = *(reinterpret_cast<const float4 *>(chain_j + L) + 1);
-						if (slab_box(a, b, beam, 1.0f) && beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) {
-							mask_j |= 1u << L;
-							if (!(__float_as_uint(b.w) & kBehind)) front_j |= 1u << L;
+						if (slab_box(a, b, beam, 1.0f)) {
+							if (__float_as_uint(b.w) & kBehind) mask_j |= 1u << L;
+							else if (beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) { mask_j |= 1u << L; front_j |= 1u << L; }
 						}
 					}
 				}
@@ -377,30 +383,31 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				// Triangle i lies 1e-5 BEHIND the origin along the ray (t = −1e-5 up to rounding of relative size 1e-15/c1): it
 				// cannot be hit unless the ray all but grazes it — then it is tested like any other, and so is everything
 				// behind the two planes.
-				const bool graze_i = !(c1 > 1e-3), graze_j = !(c2 > 1e-3);
-				if (walk && (graze_i || S.absmax > 1e4f)) push((int)~(mi.leafpos << 3));
-				const uint32_t s_i = graze_i ? mask_i : front_i, s_j = graze_j ? mask_j : front_j;
-				const uint32_t um_i = __ballot(walk && graze_i) ? um_i_all : um_i_front, um_j = __ballot(walk && graze_j) ? um_j_all : um_j_front;
+				const bool graze = !(c1 > 1e-3 && c2 > 1e-3);
+				if (walk && (graze || S.absmax > 1e4f)) push((int)~(mi.leafpos << 3));
+				const uint32_t s_i = graze ? mask_i : front_i, s_j = graze ? mask_j : front_j;
+				const bool any_graze = __ballot(walk && graze) != 0ull;
+				const uint32_t um_i = any_graze ? um_i_all : um_i_front, um_j = any_graze ? um_j_all : um_j_front;
 				const uint32_t own_j = s_j & ~low;
 				// the siblings the beam met, against THIS ray (exact slab test, bounded by the hit on j)
 				for (uint32_t m = um_i; m; m &= m - 1u) { // wave-uniform
 					FF_COUNT(1, 1);
 					const uint32_t L = (uint32_t)__builtin_ctz(m);
 					const float4 a = *reinterpret_cast<const float4 *>(chain_i + L), b = *(reinterpret_cast<const float4 *>(chain_i + L) + 1);
-					if (walk && ((s_i >> L) & 1u) && slab_box(a, b, rs, tb0)) push(__float_as_int(a.w));
+					if (walk && ((s_i >> L) & 1u) && slab_box(a, b, rs, tb0)) { push(__float_as_int(a.w)); FF_COUNT(16 + L, 1); }
 				}
 				for (uint32_t m = um_j; m; m &= m - 1u) { // wave-uniform
 					FF_COUNT(2, 1);
 					const uint32_t L = (uint32_t)__builtin_ctz(m);
 					const float4 a = *reinterpret_cast<const float4 *>(chain_0 + L), b = *(reinterpret_cast<const float4 *>(chain_0 + L) + 1);
-					if (walk && ((s_j >> L) & 1u) && slab_box(a, b, rs, tb0)) push(__float_as_int(a.w));
+					if (walk && ((s_j >> L) & 1u) && slab_box(a, b, rs, tb0)) { push(__float_as_int(a.w)); FF_COUNT(48 + L, 1); }
 				}
 				for (uint32_t m = walk ? own_j : 0u; __ballot(m != 0u) != 0ull; m &= m - 1u) { // per lane
 					FF_COUNT(3, 1);
 					if (m) {
 						const uint32_t L = (uint32_t)__builtin_ctz(m);
 						const float4 a = *reinterpret_cast<const float4 *>(chain_j + L), b = *(reinterpret_cast<const float4 *>(chain_j + L) + 1);
-						if (slab_box(a, b, rs, tb0)) push(__float_as_int(a.w));
+						if (slab_box(a, b, rs, tb0)) { push(__float_as_int(a.w)); FF_COUNT(48 + L, 1); }
 					}
 				}
 				FF_COUNT_LANES(8, from_root); FF_COUNT(4, __popcll(__ballot(sp > 0))); FF_COUNT(14, __popcll(__ballot(sp > 1))); FF_COUNT(15, __popcll(__ballot(sp > 2)));
@@ -642,6 +649,7 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	P->d_chain = d_chain; P->d_meta = d_meta; P->d_dfs = d_dfs;
 	P->n_groups = n_groups;
 	P->chain_entries = W.chain.size();
+	P->plane_delta = W.flags_on ? W.delta : -1.0;
 	P->ff_ready = true;
 	return 0;
 }
@@ -696,8 +704,8 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 
 #ifdef RTMI_FF_COUNT
 // diagnostic builds: reads and clears the work counters
-int rtmi_debug_ff_counts(uint64_t out[16]) {
-	unsigned long long z[16] = {0};
+int rtmi_debug_ff_counts(uint64_t out[96]) {
+	unsigned long long z[96] = {0};
 	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ff_counts), sizeof z) != hipSuccess) return fail("rtmi_debug_ff_counts: copy failed");
 	if (hipMemcpyToSymbol(HIP_SYMBOL(g_ff_counts), z, sizeof z) != hipSuccess) return fail("rtmi_debug_ff_counts: clear failed");
 	return 0;

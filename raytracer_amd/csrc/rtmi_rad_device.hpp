@@ -23,6 +23,7 @@ struct rtmi_patches {
 	uint32_t *d_dfs = nullptr; // patch ids in depth-first leaf order, padded with RTMI_MISS to a multiple of 64
 	uint32_t n_groups = 0;     // 64-patch groups of d_dfs
 	uint64_t chain_entries = 0;
+	double plane_delta = -1.0; // tolerance of the "behind the patch's plane" tests, < 0: the tests are off
 };
 
 namespace rtmi {

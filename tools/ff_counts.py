@@ -13,7 +13,7 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 74
 verts, normals, light = workloads.closed_box(k)
 box = rt.Scene(verts)
 rad = rad = rt.Radiosity(box, normals, None)
-out = (C.c_uint64 * 16)()
+out = (C.c_uint64 * 96)()
 rad.findFormFactor(samples=10, seed=1, row0=1000, n_rows=rows)
 torch.cuda.synchronize()
 rt.lib.rtmi_debug_ff_counts(out)
@@ -24,3 +24,7 @@ names = ["sample iterations (wave)", "um_i loop iterations", "um_j loop iteratio
 it = max(1, c[13])
 for n, v in zip(names, c):
     print("%-32s %14d   per ray-iteration %.3f" % (n, v, v / it))
+print("per pair-row (wave): beam-walk visits %.2f, path-i levels %.2f, shared path-j levels %.2f, own path-j levels %.2f" % (
+    c[80] * 10.0 / c[0], c[81] * 10.0 / c[0], c[82] * 10.0 / c[0], c[10] * 10.0 / c[0]))
+print("sibling boxes hit by a ray, by level (lane count): path i", [int(x) for x in c[16:40]])
+print("                                                   path j", [int(x) for x in c[48:72]])
