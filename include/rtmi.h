@@ -71,8 +71,8 @@ const char *rtmi_last_error(void);
 int rtmi_device_count(void);
 
 /* ---- the triangle test on its own ------------------------------------------------------------------
- * Replaces double triangle_intersection(orig, dir, v0, v1, v2, planeNormal, u, v)
- * (Render2/object.cpp:29-60, external linkage) on n independent pairs, host pointers:
+ * Replaces double triangle_intersection(orig, dir, planeNormal, v0, v1, v2, u, v)
+ * (Render2/object.cpp:29-35, external linkage; planeNormal is unused there) on n independent pairs, host pointers:
  * o, d: n × 3; tri: n × 9 (v0, v1, v2); t[k] = 0.0 means miss; u, v are in/out and are written only
  * as far as the reference writes them before each early return. */
 int rtmi_triangle_intersection(uint64_t n, const double *o, const double *d, const double *tri, double *t, double *u,
@@ -87,6 +87,13 @@ int rtmi_triangle_intersection(uint64_t n, const double *o, const double *d, con
 rtmi_scene *rtmi_scene_create(const double *tri_xyz, const uint32_t *tri_object, uint64_t n_tris);
 void rtmi_scene_destroy(rtmi_scene *);
 int rtmi_scene_get_info(const rtmi_scene *, rtmi_scene_info *out);
+/* A traversal wave that cannot finish (corrupt hierarchy, NaN rays) gives up after a bounded number of iterations per
+ * ray instead of hanging the GPU, and raises the scene's error word; its launch leaves records unwritten.  Every later
+ * entry point on the scene then fails with that message (sticky, like a device fault); rtmi_scene_check asks directly —
+ * call it after synchronising the streams whose results you are about to trust.  No reference counterpart (the
+ * reference's recursion cannot loop).  Launches of one scene may overlap on any number of streams (up to 256 different
+ * streams per scene): each stream has its own work-queue counter. */
+int rtmi_scene_check(const rtmi_scene *);
 
 /* ---- closest hit --------------------------------------------------------------------------------
  * Replaces bool Scene::Cast(const Ray&, HitInfo&) (Render2/scene.cpp:159-207) and
@@ -189,7 +196,7 @@ int rtmi_soft_shadow_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *
  * Center(GetBox(light)) and material->emission (shader.cpp:486-489).  Light 0 casts the shadows (shader.cpp:120).
  * object_materials[k] belongs to sceneObjects[k] = the tri_object ids the scene was created with.
  * tri_normals: n_tris × 3, the reference's triNormal per ORIGINAL triangle (host pointer, copied).
- * A shader holds a workspace (at most about RTMI_SHADE_WS_MB, default 4096, MiB; a frame is cut into chunks that
+ * A shader holds a workspace (at most about RTMI_SHADE_WS_MB, default 8192, MiB; a frame is cut into chunks that
  * fit): calls on the same shader must not overlap. */
 typedef struct rtmi_material {
 	double diffuse[3], specular[3], ambient[3], reflectivity[3], translucency[3];

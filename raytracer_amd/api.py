@@ -73,7 +73,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_
 
 # every symbol include/rtmi.h declares (tests check the library exports exactly these)
 SYMBOLS = [
-    "rtmi_last_error", "rtmi_device_count", "rtmi_triangle_intersection", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_get_info",
+    "rtmi_last_error", "rtmi_device_count", "rtmi_triangle_intersection", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_get_info", "rtmi_scene_check",
     "rtmi_closest_hit", "rtmi_closest_hit_dev", "rtmi_camera_setup", "rtmi_primary_closest_hit_dev",
     "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev", "rtmi_shadow_occlusion_dev", "rtmi_debug_check_hierarchy",
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
@@ -104,6 +104,7 @@ def _load():
     L.rtmi_scene_destroy.argtypes = [vp]
     L.rtmi_scene_destroy.restype = None
     L.rtmi_scene_get_info.argtypes = [vp, C.POINTER(rtmi_scene_info)]
+    L.rtmi_scene_check.argtypes = [vp]
     L.rtmi_closest_hit.argtypes = [vp, vp, u64, vp]
     L.rtmi_closest_hit_dev.argtypes = [vp, vp, u64, vp, vp]
     L.rtmi_any_hit.argtypes = [vp, vp, u64, vp]
@@ -277,6 +278,10 @@ class Scene:
             raise RtmiError(lib.rtmi_last_error().decode())
         self.handle = C.c_void_p(h)
         return True
+
+    def check(self):
+        """rtmi_scene_check: raises if a launch on this scene gave up (call after synchronising)."""
+        _check(lib.rtmi_scene_check(self.handle))
 
     def info(self):
         out = rtmi_scene_info()

@@ -49,7 +49,7 @@ struct __attribute__((aligned(16))) GTri {
 constexpr int kStackDepth = 32;   // cap on the depth of the binary hierarchy (builder); the LDS stack of a launch is sized per scene
 constexpr int kBlock = 256;       // threads per workgroup in every traversal kernel
 constexpr int kSentinel = INT32_MIN;      // lane state: no node left (ray finished, or lane idle)
-constexpr uint32_t kGuard = 1u << 26;      // wave-iterations after which trace_queue gives up (safety net)
+constexpr uint32_t kGuard = 1u << 26;      // default of SceneDev::guard: wave-iterations per ray after which a traversal gives up (safety net)
 #ifndef RTMI_NODE_STEPS
 #define RTMI_NODE_STEPS 3
 #endif
@@ -75,7 +75,12 @@ struct SceneDev {
 	const GTri *tris;
 	int32_t root_ref; // kSentinel for an empty scene
 	float absmax;     // max |coordinate| of the scene bounds (for the per-ray box padding)
+	uint32_t guard;   // wave-iterations a traversal may spend on one ray (kGuard; RTMI_GUARD overrides it, tests)
+	int *error;       // host-mapped word, set to 1 when a wave gives up: the host entries report it (rtmi_scene_check)
 };
+
+// A wave that cannot finish must still end — and must not look like success: it raises the scene's error word.
+__device__ __forceinline__ void give_up(const SceneDev &S) { __hip_atomic_store(S.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // ---------------------------------------------------------------- exact triangle test
 // Render2/object.cpp:29-60 in double, same operation order; inclusive edges; 0.0 = miss.
@@ -308,7 +313,7 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 	uint32_t tk = 0, tend = 0;
 	// All lanes start together and the wave runs until its last ray is done; per iteration it takes ONE node
 	// step or ONE triangle step, whichever more lanes wait for (see trace_queue for the refilling variant).
-	for (uint32_t guard = 0; guard < kGuard; ++guard) {
+	for (uint32_t guard = 0;; ++guard) {
 		if (cur < 0 && cur != kSentinel && cur != kLeaf) {
 			const uint32_t code = ~(uint32_t)cur;
 			tk = code >> 3;
@@ -317,6 +322,7 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 		}
 		const int n_node = __popcll(__ballot(cur >= 0)), n_leaf = __popcll(__ballot(cur == kLeaf));
 		if (n_node + n_leaf == 0) break;
+		if (guard >= S.guard) { give_up(S); h.t = 0.0; h.pos = RTMI_MISS; break; } // never reached on valid input
 		if (n_node >= n_leaf) {
 			if (cur >= 0) {
 				if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
@@ -421,6 +427,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 				const unsigned long long idle = __ballot(!have);
 				const uint32_t nidle = (uint32_t)__popcll(idle);
 				if (nidle > 0) {
+					guard = 0; // the budget is per ray: a wave that keeps starting new rays keeps going
 					// Items come from the wave's own range [w_next, w_end); when that runs short the wave takes the
 					// next kQueueChunk items from the launch's counter (one atomic per chunk, not per refill: thousands
 					// of waves adding to one address was measured to serialise).
@@ -471,7 +478,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 			tend = tk + (code & 7u) + 1u;
 			cur = kLeaf;
 		}
-		if (++guard > kGuard) break; // a wave that cannot finish must still end: never reached on valid input
+		if (++guard > S.guard) { give_up(S); break; } // a wave that cannot finish must still end: never reached on valid input
 		// Vote: the wave runs ONE node step or ONE triangle step per iteration, whichever has more lanes
 		// waiting (a triangle step costs about twice a node step).  Lanes of the other kind simply wait, so
 		// no lane ever runs ahead speculatively and the visited set is exactly the sequential one.

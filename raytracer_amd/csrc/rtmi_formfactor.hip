@@ -157,7 +157,8 @@ __device__ __forceinline__ void trace_from(const SceneDev &S, const RayF &rf, do
                                            double &best, uint32_t &pos, int cur, int sp, int *stack) {
 	float tbest = f32_above(best);
 	uint32_t tk = 0, tend = 0;
-	for (uint32_t guard = 0; guard < kGuard; ++guard) {
+	for (uint32_t guard = 0;; ++guard) {
+		if (guard >= S.guard) { give_up(S); break; } // never reached on valid input
 		if (cur < 0 && cur != kSentinel && cur != kLeaf) {
 			const uint32_t code = ~(uint32_t)cur;
 			tk = code >> 3;
@@ -225,25 +226,30 @@ RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx
 }
 
 #ifndef RTMI_FF_WAVES
-#define RTMI_FF_WAVES 4
+#define RTMI_FF_WAVES 3
 #endif
 // Workgroup = ONE group of 64 patches j (blockIdx.x); its four waves take four consecutive bands of rows i, so the group's
 // per-lane tables are fetched once per workgroup and shared through the L1.  Columns j < n_patches only; the light's row
 // (i == n_patches) is zero (:391-393), the diagonal too (:382).
-// stack: 2·(depth + 1) entries per lane — up to depth + 1 sibling subtrees waiting, and the traversal inside one of them.
+// stack: pend_cap + depth + 1 entries per lane — sibling subtrees waiting, and the traversal inside one of them.
 // (The tables come as separate __restrict__ pointers: only then does the compiler know that the stores to F cannot change
 // them, and fetches everything that depends on i alone with scalar loads.)
 RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const double *__restrict__ p_verts, const double *__restrict__ p_normals,
                                                            const double *__restrict__ p_area, uint32_t p_n, const ChainEntry *__restrict__ t_chain,
                                                            const PatchMeta *__restrict__ t_meta, const uint32_t *__restrict__ t_dfs,
                                                            uint32_t samples, uint64_t seed, uint32_t row0, uint32_t n_rows, uint32_t band_rows,
-                                                           float margin, uint32_t pend_cap, float *__restrict__ F, uint64_t ld) {
+                                                           float margin, uint32_t pend_cap, uint32_t n_groups, float *__restrict__ F, uint64_t ld) {
 	struct { const double *verts, *normals, *area; uint32_t n; } P = {p_verts, p_normals, p_area, p_n};
 	struct { const ChainEntry *chain; const PatchMeta *meta; const uint32_t *dfs; } T = {t_chain, t_meta, t_dfs};
 	extern __shared__ int stack_all[];
 	int *stack = stack_all + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t g = blockIdx.x;
+	// Workgroups are dealt to the 8 XCDs round-robin (linear id mod 8), each with its own L2.  Groups that are neighbours in
+	// depth-first order fill the same 128-byte lines of a row of F (their patch ids interleave), so XCD x takes the x-th
+	// contiguous eighth of the groups: the partial lines of neighbouring groups meet in ONE L2 and leave it merged.
+	const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
+	const uint32_t g = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+	if (g >= n_groups) return; // the padded tail of the last eighth
 	const uint32_t band = blockIdx.y * (kBlock / 64u) + uniform_u32(threadIdx.x >> 6);
 	const uint32_t r_begin = band * band_rows, r_end = min(n_rows, r_begin + band_rows);
 	if (r_begin >= n_rows) return; // whole wave
@@ -680,18 +686,24 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		hipLaunchKernelGGL(k_form_factors_flat, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes_binary, st, s->dev, pdev(P), samples, seed, row0,
 		                   n_rows, d_F, ld);
 	} else {
-		if (build_ff_tables(P, who)) return -1;
+		try {
+			if (build_ff_tables(P, who)) return -1;
+		} catch (const std::exception &e) {
+			return fail(std::string(who) + ": building the path tables: " + e.what());
+		}
 		uint32_t band = std::max(1u, env_uint("RTMI_FF_BAND", 64));
 		while ((n_rows + band - 1) / band > 4u * 65535u) band *= 2;
 		const FFTables T = {static_cast<const ChainEntry *>(P->d_chain), static_cast<const PatchMeta *>(P->d_meta), P->d_dfs, P->n_groups};
 		// beam margin: the 1e-5 origin offset, the exact test's per-ray pad (<= 2^-17·absmax) and the fp32 roundings of both
 		const float margin = 1.52587890625e-05f * s->dev.absmax + 1e-4f;
 		const uint32_t n_bands = (n_rows + band - 1) / band;
-		const dim3 grid(P->n_groups, (n_bands + kBlock / 64 - 1) / (kBlock / 64));
-		const uint32_t pend_cap = s->info.max_depth + 1u; // siblings that may wait on a lane's stack; as many entries again serve the traversal
-		const uint32_t lds = 2u * (s->info.max_depth + 1u) * kBlock * (uint32_t)sizeof(int);
+		const dim3 grid((P->n_groups + 7u) / 8u * 8u, (n_bands + kBlock / 64 - 1) / (kBlock / 64));
+		// a lane's stack: up to pend_cap sibling subtrees waiting (more is rare: that ray starts over from the root) + the
+		// depth + 1 entries the traversal inside one of them can need
+		const uint32_t pend_cap = std::min(s->info.max_depth + 1u, std::max(1u, env_uint("RTMI_FF_PEND", 8)));
+		const uint32_t lds = (s->info.max_depth + 1u + pend_cap) * kBlock * (uint32_t)sizeof(int);
 		hipLaunchKernelGGL(k_form_factors, grid, dim3(kBlock), lds, st, s->dev, (const double *)P->d_verts, (const double *)P->d_normals,
-		                   (const double *)P->d_area, P->n, T.chain, T.meta, T.dfs, samples, seed, row0, n_rows, band, margin, pend_cap, d_F, ld);
+		                   (const double *)P->d_area, P->n, T.chain, T.meta, T.dfs, samples, seed, row0, n_rows, band, margin, pend_cap, P->n_groups, d_F, ld);
 	}
 	if (launch_check(who)) return -1;
 	if (light_center) {

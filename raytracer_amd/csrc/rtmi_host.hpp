@@ -1,7 +1,9 @@
 // Host-side declarations shared by the translation units of librtmi.
 #pragma once
 #include <atomic>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include "bvh_build.hpp"
 #include "rtmi_device.hpp"
@@ -13,8 +15,13 @@ struct rtmi_scene {
 	uint32_t stack_bytes;        // dynamic LDS of the traversal kernels: room for the deepest path of either hierarchy, ints per lane
 	uint32_t stack_bytes_binary; // ... of the kernels that walk the binary nodes only: (depth + 1) ints per lane
 	rtmi_scene_info info;
-	int *d_queue;                     // ring of work-queue counters, one per launch in flight (kQueueSlots)
-	std::atomic<uint32_t> next_slot;
+	int *d_queue;                     // work-queue counters: ONE PER STREAM that has launched on this scene (kQueueSlots of them).
+	                                  // Launches on one stream are ordered, so they can share a counter (zeroed on the stream
+	                                  // before each kernel); launches on different streams never share one — no in-flight limit.
+	std::mutex queue_mutex;
+	std::unordered_map<void *, uint32_t> stream_slot;
+	std::unordered_map<const void *, int> blocks_per_cu; // hipOccupancyMaxActiveBlocksPerMultiprocessor per (kernel) at stack_bytes of LDS
+	int *h_error;                     // host-mapped word a kernel sets when a wave gives up (SceneDev::error points at it)
 	int n_cus;
 	uint32_t n_objects; // 1 + the largest tri_object seen at creation (materials are looked up by it)
 	double *d_v1_orig; // n_tris × 3: triVert1 of every triangle in ORIGINAL order (hit points, object.cpp:23)
@@ -39,7 +46,7 @@ int fail(const std::string &msg);        // records msg for rtmi_last_error(), r
 int launch_check(const char *who);
 int check_scene(const rtmi_scene *s, const char *who); // NULL / wrong current device -> -1
 unsigned env_uint(const char *name, unsigned dflt); // tuning overrides from the environment
-Tune refill_threshold();                          // RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF       // hipGetLastError() after a launch -> 0 / -1
+Tune refill_threshold();                          // RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF, read once per process
 // ray queries whose ray count lives on the device: min(cap, *d_n · mul) rays of the buffer are traced
 int closest_hit_counted(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t cap, const uint32_t *d_n, uint32_t mul, rtmi_hit *d_out,
                         void *stream, const char *who);

@@ -258,7 +258,8 @@ __device__ __forceinline__ void display_trace_bvh(const SceneDev &S, const rtmi_
 	auto bound = [&]() { return hit < 0 ? 3.0e38f : f32_above((dist / dn) * (1.0 + 1e-6)); };
 	float tb = bound();
 	int sp = 0, cur = S.root_ref;
-	for (uint32_t guard = 0; cur != kSentinel && guard < kGuard; ++guard) {
+	for (uint32_t guard = 0; cur != kSentinel; ++guard) {
+		if (guard >= S.guard) { give_up(S); break; } // never reached on valid input
 		if (cur >= 0) {
 			const QNode *np = S.nodes + cur;
 			const uint4 a = np->a, b = np->b;
@@ -463,7 +464,16 @@ using namespace rtmi;
 
 extern "C" {
 
+static rtmi_patches *patches_create(rtmi_scene *s, const double *verts, const double *normals);
 rtmi_patches *rtmi_patches_create(rtmi_scene *s, const double *verts, const double *normals) {
+	try {
+		return patches_create(s, verts, normals);
+	} catch (const std::exception &e) { // no exception crosses the C boundary (std::bad_alloc of the host tables)
+		fail(std::string("rtmi_patches_create: ") + e.what());
+		return nullptr;
+	}
+}
+static rtmi_patches *patches_create(rtmi_scene *s, const double *verts, const double *normals) {
 	if (!s || !verts || !normals) { fail("rtmi_patches_create: NULL argument"); return nullptr; }
 	int dev = -1;
 	if (hipGetDevice(&dev) != hipSuccess || dev != s->device) { fail("rtmi_patches_create: wrong current device"); return nullptr; }

@@ -290,11 +290,14 @@ unsigned env_uint(const char *name, unsigned dflt) {
 	return v > 0 ? (unsigned)v : dflt;
 }
 
-Tune refill_threshold() {
-	Tune t;
-	t.thresh = (int)std::min(64u, env_uint("RTMI_REFILL", 16));
-	t.vote_node = (int)env_uint("RTMI_VOTE_NODE", 1);
-	t.vote_leaf = (int)env_uint("RTMI_VOTE_LEAF", 3);
+Tune refill_threshold() { // the tuning environment is read once
+	static const Tune t = [] {
+		Tune x;
+		x.thresh = (int)std::min(64u, env_uint("RTMI_REFILL", 16));
+		x.vote_node = (int)env_uint("RTMI_VOTE_NODE", 1);
+		x.vote_leaf = (int)env_uint("RTMI_VOTE_LEAF", 3);
+		return x;
+	}();
 	return t;
 }
 
@@ -325,12 +328,24 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	s->d_v1_orig = nullptr;
 	s->xyz_hash = hash_doubles(xyz, 9 * n);
 	s->d_queue = nullptr;
-	s->next_slot = 0;
+	s->h_error = nullptr;
+	s->dev.guard = env_uint("RTMI_GUARD", kGuard);
+	s->dev.error = nullptr;
 	{
 		hipDeviceProp_t prop;
 		s->n_cus = (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
 	}
 	if (hipMalloc(&s->d_queue, kQueueSlots * sizeof(int)) != hipSuccess) { delete s; fail("rtmi_scene_create: hipMalloc failed"); return nullptr; }
+	// the error word lives in host memory the device can write: the host reads it without a copy
+	if (hipHostMalloc((void **)&s->h_error, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+	    hipHostGetDevicePointer((void **)&s->dev.error, s->h_error, 0) != hipSuccess) {
+		if (s->h_error) (void)hipHostFree(s->h_error);
+		(void)hipFree(s->d_queue);
+		delete s;
+		fail("rtmi_scene_create: hipHostMalloc failed");
+		return nullptr;
+	}
+	*s->h_error = 0;
 	// binary hierarchy (display pass): one push per inner node on a root-to-leaf path at most; the 4-wide one may need more
 	s->stack_bytes = s->stack_bytes_binary = (bvh.depth + 1u) * kBlock * (uint32_t)sizeof(int);
 	if (n == 0) return s;
@@ -339,13 +354,13 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	Wide4 wide;
 	{
 		std::string err;
-		if (build_wide(bvh, wide, err, threads)) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: " + err); return nullptr; }
+		if (build_wide(bvh, wide, err, threads)) { (void)hipHostFree(s->h_error); (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: " + err); return nullptr; }
 	}
 	static_assert(sizeof(WideNode) == sizeof(WNode), "host and device layout of the 4-wide node");
 	const std::vector<uint32_t> &leaf_pos = wide.leaf_pos;
 	const std::vector<WideNode> &wnodes = wide.nodes;
 	const uint32_t wide_need = wide.stack_need;
-	if ((wide_need + 1u) * kBlock * sizeof(int) > 64u * 1024u) { (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: BVH deeper than the traversal stack"); return nullptr; }
+	if ((wide_need + 1u) * kBlock * sizeof(int) > 64u * 1024u) { (void)hipHostFree(s->h_error); (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: BVH deeper than the traversal stack"); return nullptr; }
 	s->stack_bytes = (std::max(bvh.depth, wide_need) + 1u) * kBlock * (uint32_t)sizeof(int);
 	if (env_uint("RTMI_VERBOSE", 0))
 		std::fprintf(stderr, "rtmi_scene_create: %zu binary nodes of depth %u, %zu 4-wide nodes needing %u stack entries, %u B of LDS per workgroup\n",
@@ -441,6 +456,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		if (d_tris) (void)hipFree(d_tris);
 		if (s->d_v1_orig) (void)hipFree(s->d_v1_orig);
 		(void)hipFree(s->d_queue);
+		(void)hipHostFree(s->h_error);
 		delete s;
 		fail("rtmi_scene_create: hipMalloc failed");
 		return nullptr;
@@ -451,7 +467,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	ok = ok && hipMemcpy(d_tris, tris.data(), tb, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(s->d_v1_orig, v1.data(), v1.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
 	if (!ok) {
-		(void)hipFree(d_nodes); (void)hipFree(d_wnodes); (void)hipFree(d_tris); (void)hipFree(s->d_v1_orig); (void)hipFree(s->d_queue);
+		(void)hipFree(d_nodes); (void)hipFree(d_wnodes); (void)hipFree(d_tris); (void)hipFree(s->d_v1_orig); (void)hipFree(s->d_queue); (void)hipHostFree(s->h_error);
 		delete s;
 		fail("rtmi_scene_create: upload failed");
 		return nullptr;
@@ -469,6 +485,9 @@ int check_scene(const rtmi_scene *s, const char *who) {
 	int dev = -1;
 	if (hipGetDevice(&dev) != hipSuccess) return fail(std::string(who) + ": hipGetDevice failed");
 	if (dev != s->device) return fail(std::string(who) + ": the scene lives on another device than the current one");
+	// sticky, like a device fault: a launch whose waves gave up left records unwritten
+	if (s->h_error && *(volatile int *)s->h_error != 0)
+		return fail(std::string(who) + ": an earlier launch on this scene gave up (a wave exceeded its iteration budget, RTMI_GUARD): its results are incomplete");
 	return 0;
 }
 
@@ -478,19 +497,41 @@ int launch_check(const char *who) {
 	return 0;
 }
 
-// One queue counter per launch, taken round-robin from the scene's ring and zeroed on the launch's stream just before
-// the kernel: launches of one scene may overlap on different streams as long as fewer than kQueueSlots are in flight.
+// The queue counter of a launch: one per STREAM (launches on a stream are ordered, so they share it; it is zeroed on the
+// stream just before the kernel).  Launches on different streams never share a counter, however many are in flight.
 int *queue_slot(rtmi_scene *s, hipStream_t st, const char *who) {
-	int *slot = s->d_queue + (s->next_slot.fetch_add(1u) % kQueueSlots);
+	uint32_t idx;
+	{
+		std::lock_guard<std::mutex> lock(s->queue_mutex);
+		auto it = s->stream_slot.find((void *)st);
+		if (it != s->stream_slot.end()) idx = it->second;
+		else {
+			if (s->stream_slot.size() >= kQueueSlots) {
+				fail(std::string(who) + ": more than " + std::to_string(kQueueSlots) + " different streams have launched on this scene");
+				return nullptr;
+			}
+			idx = (uint32_t)s->stream_slot.size();
+			s->stream_slot.emplace((void *)st, idx);
+		}
+	}
+	int *slot = s->d_queue + idx;
 	if (hipMemsetAsync(slot, 0, sizeof(int), st) != hipSuccess) { fail(std::string(who) + ": hipMemsetAsync failed"); return nullptr; }
 	return slot;
 }
 
 // Persistent grid: as many workgroups as the device holds at once (waves stay until the queue is empty), fewer for
-// launches too small to fill them.
+// launches too small to fill them.  The occupancy query is made once per kernel and scene.
 uint32_t persistent_grid_of(rtmi_scene *s, const void *kernel, uint64_t n_items) {
 	int per_cu = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, s->stack_bytes) != hipSuccess || per_cu < 1) per_cu = 4;
+	{
+		std::lock_guard<std::mutex> lock(s->queue_mutex);
+		auto it = s->blocks_per_cu.find(kernel);
+		if (it != s->blocks_per_cu.end()) per_cu = it->second;
+		else {
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, s->stack_bytes) != hipSuccess || per_cu < 1) per_cu = 4;
+			s->blocks_per_cu.emplace(kernel, per_cu);
+		}
+	}
 	const uint64_t full = (uint64_t)per_cu * (uint64_t)s->n_cus;
 	return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full, (n_items + kBlock - 1) / kBlock));
 }
@@ -633,8 +674,15 @@ int rtmi_device_count(void) {
 }
 
 rtmi_scene *rtmi_scene_create(const double *tri_xyz, const uint32_t *tri_object, uint64_t n_tris) {
-	return scene_create(tri_xyz, tri_object, n_tris);
+	try {
+		return scene_create(tri_xyz, tri_object, n_tris);
+	} catch (const std::exception &e) { // std::bad_alloc of the host build at 2^27 triangles, std::system_error of its threads
+		fail(std::string("rtmi_scene_create: ") + e.what());
+		return nullptr;
+	}
 }
+
+int rtmi_scene_check(const rtmi_scene *s) { return check_scene(s, "rtmi_scene_check"); }
 
 void rtmi_scene_destroy(rtmi_scene *s) {
 	if (!s) return;
@@ -643,6 +691,7 @@ void rtmi_scene_destroy(rtmi_scene *s) {
 	if (s->dev.tris) (void)hipFree((void *)s->dev.tris);
 	if (s->d_v1_orig) (void)hipFree(s->d_v1_orig);
 	if (s->d_queue) (void)hipFree(s->d_queue);
+	if (s->h_error) (void)hipHostFree(s->h_error);
 	delete s;
 }
 
@@ -671,7 +720,15 @@ int rtmi_soft_shadow_dev(rtmi_scene *s, const double *d_normals, const rtmi_ray 
 	return soft_shadow_dev(s, d_normals, d_rays, d_hits, n, light_center, n_points, d_contrib, d_factor, stream);
 }
 
+static int debug_check_hierarchy(const double *tri_xyz, uint64_t n_tris, uint64_t stats[4]);
 int rtmi_debug_check_hierarchy(const double *tri_xyz, uint64_t n_tris, uint64_t stats[4]) {
+	try {
+		return debug_check_hierarchy(tri_xyz, n_tris, stats);
+	} catch (const std::exception &e) {
+		return fail(std::string("rtmi_debug_check_hierarchy: ") + e.what());
+	}
+}
+static int debug_check_hierarchy(const double *tri_xyz, uint64_t n_tris, uint64_t stats[4]) {
 	const char *who = "rtmi_debug_check_hierarchy";
 	if ((n_tris > 0 && !tri_xyz) || !stats) return fail(std::string(who) + ": NULL argument");
 	if (n_tris >= kMaxFirst) return fail(std::string(who) + ": more than 2^27-1 triangles");

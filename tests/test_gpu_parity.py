@@ -390,6 +390,56 @@ def test_empty_and_degenerate_inputs(rt):
         rt.Radiosity(scene, np.zeros((0, 3)))
 
 
+def test_a_wave_that_gives_up_is_reported(rt, monkeypatch):
+    """RTMI_GUARD bounds the iterations a wave may spend on a ray (default 2^26: never reached on valid input).  With a
+    tiny budget the waves of a real frame give up: the scene's error word must say so — through rtmi_scene_check and
+    through every later entry point — instead of returning success with unwritten records."""
+    import torch
+    from raytracer_amd import workloads
+    tris = workloads.soup(3000, seed=5, edge=0.2)
+    cam = rt.Camera.from_cam14(workloads.SOUP_CAM14, (256, 128))
+    ok_scene = rt.Scene(tris)
+    good = primary_frame(rt, ok_scene, cam)
+    ok_scene.check()
+    monkeypatch.setenv("RTMI_GUARD", "3")
+    scene = rt.Scene(tris)                      # the budget is read when the scene is created
+    monkeypatch.delenv("RTMI_GUARD")
+    out = torch.zeros(cam.x_res * cam.y_res * rt.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    scene.primary_dev(cam, out.data_ptr(), tile=(64, 64), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    with pytest.raises(rt.RtmiError, match="gave up"):
+        scene.check()
+    with pytest.raises(rt.RtmiError, match="gave up"):     # sticky: later launches on the scene are refused
+        scene.primary_dev(cam, out.data_ptr(), tile=(64, 64), stream=torch.cuda.current_stream().cuda_stream)
+    assert (good["tri"] != rt.MISS).any()
+    ok_scene.check()                             # other scenes are not affected
+
+
+def test_many_launches_in_flight_on_two_streams(rt):
+    """Every stream has its own work-queue counter, so any number of launches of one scene may be in flight on
+    different streams: 2 x 300 queued launches (more than the 256 counters a scene holds) give the records of a
+    single-stream run."""
+    import torch
+    from raytracer_amd import workloads
+    tris = workloads.soup(20000, seed=6, edge=0.05)
+    scene = rt.Scene(tris)
+    cam = rt.Camera.from_cam14(workloads.SOUP_CAM14, (320, 200))
+    want = primary_frame(rt, scene, cam)
+    n = cam.x_res * cam.y_res
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[torch.zeros(n * rt.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(4)] for _ in streams]
+    torch.cuda.synchronize()
+    for k in range(300):
+        for si, st in enumerate(streams):
+            scene.primary_dev(cam, outs[si][k % 4].data_ptr(), tile=(64, 64), stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    scene.check()
+    for si in range(2):
+        for o in outs[si]:
+            got = o.cpu().numpy().view(rt.HIT_DTYPE)
+            assert np.array_equal(got["tri"], want["tri"]) and np.array_equal(got["t"], want["t"])
+
+
 @pytest.mark.parametrize("n", [11, 257, 1000])
 def test_jacobi_sweep_vs_oracle_rgb(rt, oracle, n):
     import torch
