@@ -13,9 +13,14 @@ sample's 64x64 image tiles are dealt round-robin over the ranks, no collective o
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline            the Jacobi sweep (the HBM-bound kernel of the metric's second half), 4·n_rows·n bytes/launch
-  roofline_traversal  the closest-hit kernel (VALU/L2-latency bound, neither "hbm" nor "mfma": SURVEY.md §8d)
-  solver / formfactor the 64 K-patch solve (synthetic F, row-sharded over the ranks) and form-factor build rate
+  roofline_traversal  the closest-hit kernel the headline `value` times: SURVEY.md §8d's max(flop / 157.3 TFLOP/s,
+                      cache bytes / 34.5 TB/s L2) from the algorithmic work per ray, both terms printed
+  roofline_formfactor the form-factor kernel (98 % of "form-factor + solve time"): fp64 vector-ALU bound
+  solver / formfactor the 64 K-patch solve (synthetic F, row-sharded over the ranks) and the form-factor build
   cpu_baseline        the oracle (CPU restatement, OpenMP) on a bounded sample of the same rays, N=1 only
+  cpu_baseline_radiosity  the metric's second half on the CPU: the oracle (OpenMP) on the C2 box, and the COMPILED REFERENCE's
+                      own findFormFactor / progressiveRefinement (1 core, as shipped) on its own element list
+  reference_so        false (loudly) when oracle/_ref/*.so did not travel with the tree: the "reference" legs are then absent
 """
 import argparse
 import json
@@ -28,6 +33,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
+FP64_PEAK_TFLOPS = 78.6        # MI355X_MICROARCH.md: peak FP64 vector
+L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: L2, 8 XCDs aggregate
+# Algorithmic fp64 flop of one form-factor sample: two sample points from their hashes (2 x 24), Unit(xj − xi)
+# with its length (3 + 5 + sqrt + 3 div), the two cosines and the ray origin (5 + 6 + 6) = 77; and per ray that is shot
+# (both cosines positive): the reference's Möller–Trumbore on triangle j (46), hit point (22), |p − xj| (9), delF (5) = 82.
+FLOP_FF_SAMPLE = 77.0
+FLOP_FF_RAY = 82.0
 # algorithmic work per traversal event: one node visit = the four fp32 slab tests of a 4-wide node,
 # one triangle test = the reference's Möller–Trumbore in fp64 (priced at 2 fp32-equivalents per flop)
 FLOP_NODE_VISIT = 87.0          # 4 boxes x (6 fma = 12 flop + 6 min/max) + per node 6 fma + 3 ldexp
@@ -149,21 +161,30 @@ def main():
     l2_bytes_per_ray = (visits * BYTES_NODE + tests * BYTES_TRI) / n_pix + BYTES_HIT
     rays_per_launch = rays_rank / spp
     trav_tflops = flop_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e12
+    cache_gbs = l2_bytes_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e9
+    valu_frac, cache_frac = trav_tflops / FP32_PEAK_TFLOPS, cache_gbs / L2_PEAK_GBS
+    # fraction of roofline = max(flop / vector-ALU peak, cache bytes / L2 bandwidth), algorithmic work per ray
     roofline_traversal = {
-        "kernel": "k_primary_closest", "bound": "valu", "achieved": round(trav_tflops, 3), "peak": FP32_PEAK_TFLOPS,
-        "unit": "TFLOP/s (fp32-equivalent; fp64 flop = 2)", "frac": round(trav_tflops / FP32_PEAK_TFLOPS, 4),
+        "kernel": "k_primary_closest", "bound": "l2" if cache_frac >= valu_frac else "valu",
+        "achieved": round(cache_gbs if cache_frac >= valu_frac else trav_tflops, 3),
+        "peak": L2_PEAK_GBS if cache_frac >= valu_frac else FP32_PEAK_TFLOPS,
+        "unit": "GB/s through L1/L2 (algorithmic node + triangle + hit bytes)" if cache_frac >= valu_frac else "TFLOP/s (fp32-equivalent; fp64 flop = 2)",
+        "frac": round(max(valu_frac, cache_frac), 4),
+        "frac_valu": round(valu_frac, 4), "valu_tflops": round(trav_tflops, 3), "valu_peak_tflops": FP32_PEAK_TFLOPS,
+        "frac_cache": round(cache_frac, 4), "cache_gbs": round(cache_gbs, 1), "cache_peak_gbs": L2_PEAK_GBS,
         "kernel_ms": round(kernel_ms, 4), "rays_per_launch": int(rays_per_launch),
         "node_visits_per_ray": round(visits / n_pix, 2), "tri_tests_per_ray": round(tests / n_pix, 2),
-        "cache_bytes_per_ray": round(l2_bytes_per_ray, 1),
+        "cache_bytes_per_ray": round(l2_bytes_per_ray, 1), "flop_per_ray": round(flop_per_ray, 1),
         "lane_occupancy_node_loop": round(visits / max(1, vslots), 3), "lane_occupancy_tri_loop": round(tests / max(1, tslots), 3),
         "node_step_lanes_holding_a_leaf": round(wleaf / max(1, vslots), 3), "node_step_lanes_without_a_ray": round(widle / max(1, vslots), 3),
-        "cache_gbs": round(l2_bytes_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e9, 1), "traffic": None,
+        "traffic": None,
     }
 
     # ------------------------------------------------------------------ radiosity solve, C5 (synthetic F)
     solver = None
     roofline = None
     formfactor = None
+    roofline_formfactor = None
     if not args.no_solver:
         n = args.patches
         row0, n_rows, _ = multi.rows_of_rank(n, rank, world)
@@ -203,15 +224,18 @@ def main():
         if os.path.exists(tr):
             try:
                 tj = json.load(open(tr))
+                # `traffic` is a STORED measurement (PMC passes of an earlier run of this same launch shape), not of this run
                 if tj.get("k_jacobi_sweep", {}).get("bytes_per_launch") == bytes_launch:
                     roofline["traffic"] = tj["k_jacobi_sweep"]["hbm_bytes"]
+                    roofline["traffic_source"] = "stored: profiles/%s_rocprof.md (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same launch shape)" % tj["k_jacobi_sweep"].get("source", "?")
                 if tj.get("k_primary_closest", {}).get("rays_per_launch") == int(rays_per_launch):
                     roofline_traversal["traffic"] = tj["k_primary_closest"]["hbm_bytes"]
                     # PMC shares of the same kernel (rocprofv3 passes of tools/profile_gpu.sh; profiles/<source>_rocprof.md)
                     for key in ("l2_hit_rate", "valu_active_share_of_wave_cycles", "wait_any_share_of_wave_cycles", "lanes_active_per_valu_instruction"):
                         if key in tj["k_primary_closest"]:
                             roofline_traversal[key] = tj["k_primary_closest"][key]
-                    roofline_traversal["pmc_source"] = "profiles/%s_rocprof.md" % tj["k_primary_closest"].get("source", "?")
+                    roofline_traversal["pmc_source"] = "stored: profiles/%s_rocprof.md" % tj["k_primary_closest"].get("source", "?")
+                    roofline_traversal["traffic_source"] = roofline_traversal["pmc_source"]
             except Exception:
                 pass
         # (b) the whole solve to 1e-4 relative change (north star), exchange included when N > 1
@@ -263,18 +287,56 @@ def main():
                                                   Fb[first:].data_ptr(), ldb, stream)
                 if rc != 0:
                     raise SystemExit(rt.lib.rtmi_last_error().decode())
-            build(0, min(8, nr_s))                                                   # warm-up
+            build(0, min(8, nr_s))                                                   # warm-up (builds the path tables too)
             barrier()
+            fe0, fe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_launch = 0
             t0 = time.perf_counter()
+            fe0.record()
             for first in range(0, nr_s, 4096):
                 build(first, min(4096, nr_s - first))
+                n_launch += 1
+            fe1.record()
             barrier()
             ff_s = max_over_ranks(time.perf_counter() - t0)
-            vis_rays = 10.0 * (rad.numOfElements - 1) * (nb - 1 if full else nr_s * world)
-            formfactor = {"patches": rad.numOfElements, "rows_built_per_rank": nr_s, "seconds": round(ff_s, 4),
+            ff_kernel_ms = fe0.elapsed_time(fe1) / n_launch      # k_form_factors (+ the light column's 4096 rays) per launch, HIP events
+            box.check()
+            ne = rad.numOfElements
+            vis_rays = 10.0 * (ne - 1) * (nb - 1 if full else nr_s * world)
+            # samples that shoot a ray: both cosines positive <=> the two patches do not lie in one plane facing the same way
+            # (a box: pairs on different walls); counted on the host from the normals
+            _, inv, cnt = np.unique(np.round(normals, 9), axis=0, return_inverse=True, return_counts=True)
+            shoot = 1.0 - float((cnt.astype(np.float64) ** 2).sum()) / float(ne) ** 2
+            pairs_launch = 10.0 * (ne - 1) * min(4096, nr_s)
+            ff_tflops = (FLOP_FF_SAMPLE + FLOP_FF_RAY * shoot) * pairs_launch / (ff_kernel_ms * 1e-3) / 1e12
+            roofline_formfactor = {
+                "kernel": "k_form_factors", "bound": "valu (fp64 vector)", "achieved": round(ff_tflops, 3), "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s fp64 (algorithmic: %.0f flop per sample + %.0f per ray shot; divisions and roots count 1)" % (FLOP_FF_SAMPLE, FLOP_FF_RAY),
+                "frac": round(ff_tflops / FP64_PEAK_TFLOPS, 4), "kernel_ms": round(ff_kernel_ms, 3), "rows_per_launch": min(4096, nr_s),
+                "pair_samples_per_launch": pairs_launch, "rays_shot_fraction": round(shoot, 4),
+                "G_pair_samples_per_s": round(pairs_launch / (ff_kernel_ms * 1e-3) / 1e9, 2), "traffic": None}
+            tr = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tr):
+                try:
+                    tj = json.load(open(tr)).get("k_form_factors", {})
+                    for key in ("hbm_bytes_per_entry_fetch", "hbm_bytes_per_entry_write", "l2_hit_rate", "valu_issue_utilisation",
+                                "valu_instructions_per_pair_sample", "scratch_bytes", "vgprs"):
+                        if key in tj:
+                            roofline_formfactor[key] = tj[key]
+                    if "hbm_bytes_per_launch" in tj and tj.get("rows_per_launch") == min(4096, nr_s):
+                        roofline_formfactor["traffic"] = tj["hbm_bytes_per_launch"]
+                    if tj:
+                        roofline_formfactor["pmc_source"] = "stored: profiles/%s" % tj.get("source", "?")
+                except Exception:
+                    pass
+            formfactor = {"patches": ne, "rows_built_per_rank": nr_s, "seconds": round(ff_s, 4),
                           "pair_samples_M_per_s": round(vis_rays / ff_s / 1e6, 1), "samples_per_pair": 10,
                           "note": "a visibility ray is shot only for samples whose two cosines are positive (others add 0 whatever the ray says)",
                           "full_matrix": full, "F_GiB_per_rank": round(nr_s * ldb * 4 / 2**30, 2)}
+            # the rows tests/test_gpu_full_size.py compares with the oracle: CRC of the matrix that was just timed
+            import zlib
+            pinned = [r for r in (0, 21000, 43210, 64743) if r0 <= r < r0 + nr_s and r < ne]
+            formfactor["crc32_of_pinned_rows"] = {str(r): "%08x" % zlib.crc32(Fb[r - r0, : nb].cpu().numpy().tobytes()) for r in pinned}
             if not full:
                 formfactor["extrapolated_full_build_seconds"] = round(ff_s * nr / nr_s, 1)
             else:
@@ -319,13 +381,105 @@ def main():
                    "" if args.cpu_row_stride == 1 else "%d-th" % args.cpu_row_stride, x_res, y_res, len(d), reps, secs),
                "gpu_vs_oracle_mismatches_on_sample": mism}
 
+    # ------------------------------------------------------------------ CPU baseline of the metric's second half
+    # (i) the oracle (OpenMP, its own hierarchy) on the C2 box: form factors + direct solve, beside the GPU on the same box;
+    # (ii) the COMPILED REFERENCE's own Radiosity::findFormFactor / progressiveRefinement (1 thread, as shipped) on the
+    #      element list its BSP build makes of test1, beside the GPU on the same elements.
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref_render2.so")
+    have_ref_so = os.path.exists(ref_so)
+    if rank == 0 and not have_ref_so:
+        print("bench.py: oracle/_ref/libref_render2.so is ABSENT (it is built where /root/reference exists and travels with the "
+              "tree): every 'kind: reference' leg below is missing", file=sys.stderr, flush=True)
+    cpu_rad = None
+    if world == 1 and rank == 0 and not args.no_cpu and not args.no_solver:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle_py import Oracle
+        ora = Oracle()
+        v2, n2, l2 = workloads.closed_box(18, hole=0.3)             # C2: 12·18² patches less the ceiling opening the light shines through
+        nb2 = len(v2)
+        # GPU: whole matrix + solve
+        sc2 = rt.Scene(v2)
+        rad2 = rt.Radiosity(sc2, n2, l2)
+        rad2.findFormFactor(samples=10, light_samples=30, seed=1, row0=0, n_rows=8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        F2 = rad2.findFormFactor(samples=10, light_samples=30, seed=1)
+        torch.cuda.synchronize()
+        g_ff = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        rad2.progressiveRefinement(tol_rel=1e-7, check_every=4)
+        torch.cuda.synchronize()
+        g_sv = time.perf_counter() - t0
+        # oracle: a bounded sample of rows (about 10 s), extrapolated to the matrix; the direct solve of the GPU's F
+        hb = ora.bvh_build(v2)
+        rows_done, secs = 0, 0.0
+        same = True
+        while secs < 10.0 and rows_done < nb2:
+            k = min(64, nb2 - rows_done)
+            t0 = time.perf_counter()
+            Fo = ora.form_factors_bvh(v2, n2, 10, 1, row0=rows_done, n_rows=k, bvh=hb)
+            secs += time.perf_counter() - t0
+            same = same and bool(np.array_equal(Fo.astype(np.float32), F2[rows_done:rows_done + k, :nb2].cpu().numpy()))
+            rows_done += k
+        ora.bvh_free(hb)
+        t0 = time.perf_counter()
+        Fh = F2[:, : nb2 + 1].cpu().numpy().astype(np.float64)
+        K2 = np.eye(nb2 + 1) - 0.70 * Fh                           # radiosity.cpp:413-428; the light's row of F is zero
+        E2 = np.zeros(nb2 + 1); E2[nb2] = 68500.0
+        Bd = np.linalg.solve(K2, E2)
+        o_sv = time.perf_counter() - t0
+        Bg = rad2.B[:nb2, 0].double().cpu().numpy()
+        cpu_rad = {"c2_oracle": {"workload": "C2: closed box, %d patches, 10 samples per pair: form factors + solve" % nb2, "kind": "port",
+                                 "cores": ora.num_threads(), "formfactor_seconds": round(secs * nb2 / rows_done, 2),
+                                 "sample": "%d of %d rows through the oracle's own hierarchy = %.1f s, extrapolated" % (rows_done, nb2, secs),
+                                 "solve_seconds": round(o_sv, 3), "solve": "numpy/LAPACK direct solve of (I − rho F) B = E in double",
+                                 "gpu_formfactor_seconds": round(g_ff, 4), "gpu_solve_seconds": round(g_sv, 4), "gpu_solve_sweeps": int(rad2.stats.sweeps),
+                                 "gpu_rows_equal_oracle_rows": same,
+                                 "gpu_vs_direct_solve_rel_l2": float(np.linalg.norm(Bg - Bd[:nb2]) / np.linalg.norm(Bd[:nb2]))}}
+        rad2.close(); sc2.close()
+        if have_ref_so:
+            import tempfile
+            from oracle_py import Reference
+            g = np.load(os.path.join(ROOT, "tests", "golden", "g2_test1.npz"))
+            ref = Reference(ref_so)
+            work = tempfile.mkdtemp()
+            hr, ok = None, False
+            for _ in range(10):                       # the reference's BSP build uses an unseeded RNG and may throw
+                hr = ref.scene_from_triangles(g["tris"], g["tri_obj"], g["light_center"])
+                if ref.build_bsp(hr, work) == 0:
+                    ok = True
+                    break
+            if ok:
+                ne_r = ref.rad_setup(hr)              # elements = the leaves of the reference's BSP (radiosity.cpp:137-163)
+                ev, en, _ = ref.rad_elements(hr, ne_r)
+                r_ff = ref.rad_find_form_factor(hr)   # the reference's own Monte-Carlo fill (unseeded), seconds
+                r_sv = ref.rad_solve(hr)              # its progressiveRefinement on that F
+                sc3 = rt.Scene(ev)
+                rad3 = rt.Radiosity(sc3, en, g["light_center"])
+                rad3.findFormFactor(samples=10, light_samples=30, seed=1, row0=0, n_rows=1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rad3.findFormFactor(samples=10, light_samples=30, seed=1)
+                torch.cuda.synchronize()
+                g3_ff = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                rad3.progressiveRefinement(tol_rel=1e-7, check_every=4)
+                torch.cuda.synchronize()
+                g3_sv = time.perf_counter() - t0
+                cpu_rad["test1_reference"] = {
+                    "workload": "Render2/scenes/test1: the %d elements the reference's BSP build made of its 24 triangles (+ the light)" % ne_r,
+                    "kind": "reference", "cores": 1, "findFormFactor_seconds": round(r_ff, 3), "progressiveRefinement_seconds": round(r_sv, 7),
+                    "reference_residual": float(ref.rad_residual(hr)),
+                    "gpu_formfactor_seconds": round(g3_ff, 5), "gpu_solve_seconds": round(g3_sv, 5),
+                    "note": "the reference's sample points are unseeded: its F differs from run to run; the GPU's F on the same elements is the oracle's bit for bit (tests/test_gpu_adapter.py)"}
+                rad3.close(); sc3.close()
+
     # ------------------------------------------------------------------ C1: the compiled reference itself (configs[0])
     # The reference cannot run C3 (its BSP build is quadratic and throws on real meshes), so its own CPU path is
     # timed on its own scene: test1, 500x400 primary rays through Scene::Cast, beside the GPU on the same frame.
     # Needs oracle/_ref/libref_render2.so (built where /root/reference exists; the .so travels to the GPU box).
     c1 = None
-    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref_render2.so")
-    if world == 1 and rank == 0 and not args.no_cpu and os.path.exists(ref_so):
+    if world == 1 and rank == 0 and not args.no_cpu and have_ref_so:
         import tempfile
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         from oracle_py import Reference
@@ -441,8 +595,9 @@ def main():
                        "bvh": {"nodes": int(info.n_nodes), "leaves": int(info.n_leaves), "depth": int(info.max_depth),
                                "max_leaf": int(info.max_leaf_size), "build_seconds": round(info.build_seconds, 2),
                                "device_MB": round(info.device_bytes / 1e6, 1)}},
-            "roofline": roofline, "roofline_traversal": roofline_traversal, "solver": solver, "formfactor": formfactor,
-            "cpu_baseline": cpu, "c1_reference": c1, "frame": frame,
+            "roofline": roofline, "roofline_traversal": roofline_traversal, "roofline_formfactor": roofline_formfactor,
+            "solver": solver, "formfactor": formfactor,
+            "cpu_baseline": cpu, "cpu_baseline_radiosity": cpu_rad, "reference_so": have_ref_so, "c1_reference": c1, "frame": frame,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

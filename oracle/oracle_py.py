@@ -157,6 +157,19 @@ class Oracle:
                                   C.c_long(row0), C.c_long(n_rows), C.c_long(n), _p(F))
         return F
 
+    def form_factors_bvh(self, verts, normals, samples, seed, row0=0, n_rows=None, bvh=None):
+        """form_factors with the closest hits taken through the oracle's own hierarchy (same records, for large n)"""
+        verts = _f64(verts, (-1, 9)); normals = _f64(normals, (-1, 3))
+        n = len(verts)
+        n_rows = n - row0 if n_rows is None else n_rows
+        F = np.zeros((n_rows, n))
+        h = self.bvh_build(verts) if bvh is None else bvh
+        self.lib.rto_form_factors_bvh(h, C.c_long(n), _p(verts), _p(normals), C.c_uint32(samples), C.c_uint64(seed),
+                                      C.c_long(row0), C.c_long(n_rows), C.c_long(n), _p(F))
+        if bvh is None:
+            self.bvh_free(h)
+        return F
+
     def ff_term_points(self, verts, normals, i, j, xi, xj):
         verts = _f64(verts, (-1, 9)); normals = _f64(normals, (-1, 3)); xi = _f64(xi, (-1, 3)); xj = _f64(xj, (-1, 3))
         return self.lib.rto_ff_term_points(C.c_long(len(verts)), _p(verts), _p(normals), C.c_int32(i), C.c_int32(j),

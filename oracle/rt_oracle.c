@@ -279,15 +279,26 @@ double rto_area(const double a[3], const double b[3], const double c[3]) {
 	return len(cross(sub(ld3(b), ld3(a)), sub(ld3(c), ld3(a)))) / 2.0;
 }
 
+/* The closest hit through the oracle's own hierarchy (defined below): the same record as the scan over all triangles —
+ * the boxes only prune, the strict minimum and the smaller-index tie rule are kept — for inputs where the scan would
+ * take hours (one row of a 64 K-patch matrix is 4·10^10 triangle tests).  NULL = the scan. */
+static int32_t bvh_closest_one(const rto_bvh *b, v3 O, v3 D, double tmax, double *bt, double *pu, double *pv);
+static int32_t closest_via(const rto_bvh *b, long n, const double *verts, v3 org, v3 dir, double *t, double *u, double *v) {
+	return b ? bvh_closest_one(b, org, dir, RTO_INFINITY, t, u, v) : closest(n, verts, org, dir, RTO_INFINITY, t, u, v);
+}
+
 /* radiosity.cpp:231-262 */
-static int visible(long n, const double *verts, const double *normals, int32_t j, v3 xi, v3 yi) {
+static int visible_via(const rto_bvh *b, long n, const double *verts, const double *normals, int32_t j, v3 xi, v3 yi) {
 	v3 dir = unit(sub(yi, xi));
 	v3 org = add(xi, scl(RTO_EPSILON, dir));
 	double t, u, v;
-	int32_t h = closest(n, verts, org, dir, RTO_INFINITY, &t, &u, &v);
+	int32_t h = closest_via(b, n, verts, org, dir, &t, &u, &v);
 	if (h < 0) return 0;
 	v3 p = hit_point(org, dir, ld3(verts + 9 * h), ld3(normals + 3 * h));
 	return (len(sub(p, yi)) < RTO_EPSILON && dot(dir, ld3(normals + 3 * j)) < 0) ? 1 : 0;
+}
+static int visible(long n, const double *verts, const double *normals, int32_t j, v3 xi, v3 yi) {
+	return visible_via(NULL, n, verts, normals, j, xi, yi);
 }
 
 void rto_visible(long n, const double *verts, const double *normals, long m, const int32_t *ei, const int32_t *ej,
@@ -334,14 +345,14 @@ void rto_sample_point(const double *e, uint64_t seed, uint32_t a, uint32_t b, ui
 }
 
 /* radiosity.cpp:305-333 */
-static double ff_term(long n, const double *verts, const double *normals, int32_t i, int32_t j, uint32_t S,
-                      const double *xi, const double *xj) {
+static double ff_term_via(const rto_bvh *bvh, long n, const double *verts, const double *normals, int32_t i, int32_t j, uint32_t S,
+                          const double *xi, const double *xj) {
 	double ff = 0;
 	v3 ni = ld3(normals + 3 * i), nj = ld3(normals + 3 * j);
 	double area_j = rto_area(verts + 9 * j, verts + 9 * j + 3, verts + 9 * j + 6);
 	for (uint32_t k = 0; k < S; ++k) {
 		v3 a = ld3(xi + 3 * k), b = ld3(xj + 3 * k);
-		if (visible(n, verts, normals, j, a, b)) {
+		if (visible_via(bvh, n, verts, normals, j, a, b)) {
 			v3 ab = sub(a, b);
 			double dist2 = dot(ab, ab);
 			double c1 = dot(unit(sub(b, a)), ni);
@@ -353,6 +364,11 @@ static double ff_term(long n, const double *verts, const double *normals, int32_
 	}
 	ff = ff / ((double)S);
 	return ff * area_j;
+}
+
+static double ff_term(long n, const double *verts, const double *normals, int32_t i, int32_t j, uint32_t S,
+                      const double *xi, const double *xj) {
+	return ff_term_via(NULL, n, verts, normals, i, j, S, xi, xj);
 }
 
 double rto_ff_term_points(long n, const double *verts, const double *normals, int32_t i, int32_t j, uint32_t S,
@@ -375,6 +391,29 @@ void rto_form_factors(long n, const double *verts, const double *normals, uint32
 			F[r * ld + j] = ff_term(n, verts, normals, (int32_t)i, (int32_t)j, S, xi, xj);
 		}
 		free(xi);
+	}
+}
+
+/* The same rows with every closest hit taken through the oracle's hierarchy, columns spread over the threads
+ * (tests/test_oracle_golden.py pins it to rto_form_factors on small scenes). */
+void rto_form_factors_bvh(const rto_bvh *bvh, long n, const double *verts, const double *normals, uint32_t S, uint64_t seed,
+                          long row0, long n_rows, long ld, double *F) {
+	for (long r = 0; r < n_rows; ++r) {
+		long i = row0 + r;
+#pragma omp parallel
+		{
+			double *xi = (double *)malloc(sizeof(double) * 6 * S), *xj = xi + 3 * S;
+#pragma omp for schedule(dynamic, 64)
+			for (long j = 0; j < n; ++j) {
+				if (i == j) { F[r * ld + j] = 0.0; continue; }
+				for (uint32_t k = 0; k < S; ++k) {
+					rto_sample_point(verts + 9 * i, seed, (uint32_t)i, (uint32_t)j, k, 0, xi + 3 * k);
+					rto_sample_point(verts + 9 * j, seed, (uint32_t)i, (uint32_t)j, k, 1, xj + 3 * k);
+				}
+				F[r * ld + j] = ff_term_via(bvh, n, verts, normals, (int32_t)i, (int32_t)j, S, xi, xj);
+			}
+			free(xi);
+		}
 	}
 }
 

@@ -131,6 +131,9 @@ long rto_jacobi_rgb(long n, const float *F, const double rho[3], const double *E
 
 /* ---- CPU baseline: same closest-hit contract through a BVH (our own, binned SAH) ---- */
 typedef struct rto_bvh rto_bvh;
+/* rto_form_factors with every closest hit taken through the hierarchy (same records; for the 64 K-patch rows) */
+void rto_form_factors_bvh(const rto_bvh *, long n, const double *verts, const double *normals, uint32_t samples, uint64_t seed,
+                          long row0, long n_rows, long ld, double *F);
 rto_bvh *rto_bvh_build(long n_tris, const double *tris);
 void rto_bvh_free(rto_bvh *);
 /* identical results to rto_closest_hit (tests pin this); returns seconds, uses OpenMP threads */

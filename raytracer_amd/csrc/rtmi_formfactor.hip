@@ -637,6 +637,11 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	if (W.bad || W.dfs.size() != n) return fail(std::string(who) + ": the hierarchy is not a binary tree over the patches with one triangle per leaf");
 	if (W.chain.size() > 0xffffffffull) return fail(std::string(who) + ": path table too large");
 	const uint32_t n_groups = (n + 63u) / 64u;
+	{
+		const char *ord = std::getenv("RTMI_FF_ORDER"); // "id": groups of 64 consecutive patch ids (experiment)
+		if (ord && std::strcmp(ord, "id") == 0)
+			for (uint32_t k = 0; k < n; ++k) W.dfs[k] = k;
+	}
 	W.dfs.resize((size_t)n_groups * 64u, RTMI_MISS);
 	if (W.chain.empty()) W.chain.emplace_back(); // a one-patch scene has no siblings; keep the pointer valid
 	void *d_chain = nullptr, *d_meta = nullptr;

@@ -140,6 +140,39 @@ def test_c5_solver_known_answer_64k(rt):
     assert 5 < stats.sweeps < 60
 
 
+C5_BOX_ROWS = [0, 21000, 43210, 64743]     # first, two interior (different walls), last patch of the 64 744-patch box
+
+
+def test_c5_form_factor_rows_of_the_64k_box_equal_the_oracle(rt, oracle):
+    """The matrix bench.py builds (64 744-patch box with a ceiling opening, light above it): four of its rows, the light
+    column and the light's own row against the oracle — bit-exact in fp32.  The oracle takes its closest hits through
+    its own hierarchy here (rto_form_factors_bvh, pinned to the scan over all triangles on small scenes by
+    tests/test_oracle_golden.py): one such row is 4·10^10 triangle tests by the scan."""
+    from raytracer_amd import workloads
+    verts, normals, light = workloads.closed_box(74, hole=0.3)
+    n = len(verts)
+    assert n == 64744
+    scene = rt.Scene(verts)
+    rad = rt.Radiosity(scene, normals, light)
+    h = oracle.bvh_build(verts)
+    for r in C5_BOX_ROWS:
+        got = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=r, n_rows=1).cpu().numpy()[0]
+        want = oracle.form_factors_bvh(verts, normals, 10, 1, row0=r, n_rows=1, bvh=h)[0].astype(np.float32)
+        assert np.array_equal(got[:n].view(np.uint32), want.view(np.uint32)), "row %d" % r
+        fl = oracle.light_terms(verts, normals, light, 30, 1, mirror_bug=1, row0=r, n_rows=1)
+        assert got[n] == np.float32(fl[0])
+        assert 0.5 < float(want.sum()) < 1.1 and got[r] == 0.0
+    oracle.bvh_free(h)
+    # the light's own row is zero; rows that straddle the end of the patches
+    tail = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=n - 1, n_rows=2).cpu().numpy()
+    assert np.all(tail[1] == 0.0) and tail[0, : n].sum() > 0.5
+    # the blocks bench.py builds (4096 rows per launch) give the same rows as single-row launches
+    blk = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=20480, n_rows=4096).cpu().numpy()
+    one = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=21000, n_rows=1).cpu().numpy()[0]
+    assert np.array_equal(blk[21000 - 20480], one)
+    scene.check()
+
+
 def test_frame_path_full_size_properties(rt, oracle, monkeypatch):
     """1920x1080 frames of the 147 K-triangle studio through rtmi_render_frame_dev (depth 3, 10 AO rays): properties that
     do not depend on the size — (a) a sample of pixels equals the oracle's recursion (same seeded AO stream), (b) the

@@ -286,3 +286,21 @@ def test_g8_radiosity_display_path(oracle, stem):
     # the fixture has all three outcomes: no element (Green), back face (Black, radiosity_test only), shaded
     green = (rgb == [0, 1, 0]).all(1)
     assert green.any() and (~green & (rgb[:, 0] > 0)).sum() > 1000
+
+
+def test_form_factor_rows_through_the_oracles_hierarchy_equal_the_scan(oracle):
+    """rto_form_factors_bvh (used to check rows of the 64 K-patch matrix on the GPU box) against rto_form_factors, the scan
+    over all triangles that the golden vectors pin: same doubles, on a box with an occluder and on a random soup."""
+    sys_path_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, sys_path_root)
+    from raytracer_amd import workloads
+    vb, nb, _ = workloads.closed_box(4, hole=0.4)
+    inner = workloads._box((3.0, 2.0, 0.0), (6.0, 5.5, 4.0), 2)
+    V = np.concatenate([vb, inner]); N = np.concatenate([nb, workloads.face_normals(inner)])
+    A = oracle.form_factors(V, N, 10, 3, row0=5, n_rows=6)
+    B = oracle.form_factors_bvh(V, N, 10, 3, row0=5, n_rows=6)
+    assert np.array_equal(A, B) and (A > 0).mean() > 0.3 and (A == 0).mean() > 0.1
+    sp = workloads.soup(300, seed=3, edge=0.35)
+    Ns = workloads.face_normals(sp)
+    assert np.array_equal(oracle.form_factors(sp, Ns, 4, 9, row0=100, n_rows=3), oracle.form_factors_bvh(sp, Ns, 4, 9, row0=100, n_rows=3))

@@ -24,7 +24,8 @@ def short(name):
     return None
 
 
-lines = ["# rocprofv3 summary `%s` — `python3 bench.py --steps 5 --warmup 2 --no-cpu --ff-rows 256` on one MI355X" % tag, ""]
+lines = ["# rocprofv3 summary `%s` — `python3 bench.py --steps 5 --warmup 2 --no-cpu --ff-rows 4096` on one MI355X" % tag, "",
+         "(k_form_factors: the figures are those of the 4096-row launch — the largest dispatch — not an average with the 8-row warm-up)", ""]
 lines += ["## --kernel-trace --stats (rtmi kernels; torch helper kernels that build the synthetic inputs omitted)", "",
           "| kernel | calls | avg ms | min ms | max ms | % of GPU time |", "|---|---|---|---|---|---|"]
 for row in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))):
@@ -56,7 +57,7 @@ for k in KERNELS:
     if k not in pmc:
         continue
     lines += ["### %s" % k, "", "| counter | avg per dispatch |", "|---|---|"]
-    avg = {c: sum(v) / len(v) for c, v in pmc[k].items()}
+    avg = {c: (max(v) if k == "k_form_factors" else sum(v) / len(v)) for c, v in pmc[k].items()}
     for c in sorted(avg):
         lines.append("| %s | %.6g |" % (c, avg[c]))
     lines.append("")
@@ -91,5 +92,31 @@ if "k_primary_closest" in traffic and "hbm_bytes" in traffic["k_primary_closest"
     for key in ("l2_hit_rate", "valu_active_share_of_wave_cycles", "wait_any_share_of_wave_cycles", "lanes_active_per_valu_instruction"):
         if key in t:
             out["k_primary_closest"][key] = round(t[key], 4)
+if "k_form_factors" in traffic:
+    t = traffic["k_form_factors"]
+    a = {c: max(v) for c, v in pmc["k_form_factors"].items()}
+    n_box = 64744 + 1
+    rows = 4096
+    entries = rows * n_box
+    ff = {"rows_per_launch": rows, "source": tag + "_rocprof.md"}
+    if "fetch_raw" in t:
+        ff["hbm_bytes_per_launch"] = t["fetch_raw"] + t["write"]
+        ff["hbm_bytes_per_entry_fetch"] = round(t["fetch_raw"] / entries, 2)
+        ff["hbm_bytes_per_entry_write"] = round(t["write"] / entries, 2)
+        ff["note"] = "FETCH_SIZE uncorrected (scattered 16-byte loads: the x2 of a streaming read does not apply); WRITE_SIZE counts the one-dword-per-lane stores of a row at about twice their bytes (profiles/README.md, calibration)"
+    if "l2_hit_rate" in t:
+        ff["l2_hit_rate"] = round(t["l2_hit_rate"], 4)
+    ms = [float(r["AverageNs"]) for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))) if "k_form_factors" in r["Name"] and "flat" not in r["Name"]]
+    mx = [float(r["MaxNs"]) for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))) if "k_form_factors" in r["Name"] and "flat" not in r["Name"]]
+    if mx and "SQ_INSTS_VALU" in a:
+        # 1024 SIMDs, a wave64 vector instruction occupies its SIMD for 4 cycles, 2.4 GHz nominal
+        ff["valu_issue_utilisation"] = round(a["SQ_INSTS_VALU"] * 4.0 / (1024 * mx[0] * 1e-9 * 2.4e9), 3)
+        ff["valu_instructions_per_lane_sample"] = round(a["SQ_INSTS_VALU"] / (a["SQ_WAVES"] * 64 * 10), 1)
+        ff["kernel_ms"] = round(mx[0] / 1e6, 3)
+    g = geo.get("k_form_factors")
+    if g:
+        ff["scratch_bytes"] = int(g.get("Scratch_Size") or 0)
+        ff["vgprs"] = int(g.get("VGPR_Count") or 0) + int(g.get("Accum_VGPR_Count") or 0)
+    out["k_form_factors"] = ff
 json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 print("\n".join(lines))
