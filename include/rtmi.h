@@ -260,6 +260,13 @@ int rtmi_tone_map_dev(const double *d_rgb, uint64_t n, uint8_t *d_pixels, void *
  * (cam14 = eye, lookat, up, vpdist, x_win, y_win).  Any pointer of rtmi_scene_file_get may be NULL. */
 typedef struct rtmi_scene_file rtmi_scene_file;
 rtmi_scene_file *rtmi_scene_file_load(const char *scenes_dir, const char *stem);
+/* The same reader without the limits that keep the reference's larger assets from loading (Render2/scene.cpp:211: 512-byte
+ * lines; :400-405: the first line must be `o <object name>`; Render2/params.cpp:214: triangles and quads only):
+ * RTMI_SCENE_LENIENT takes lines of any length, any `o` / `g` name (or none), relative (negative) indices, and faces with any
+ * number of corners — v1 v2 v3 v4 v5 ... becomes (v1,v2,v3), (v3,v4,v1), (v4,v5,v1), ...: the reference's quad split, carried on.
+ * A missing .obj is an error in this mode.  flags = 0 is rtmi_scene_file_load. */
+#define RTMI_SCENE_LENIENT 1u
+rtmi_scene_file *rtmi_scene_file_load_ex(const char *scenes_dir, const char *stem, uint32_t flags);
 void rtmi_scene_file_free(rtmi_scene_file *);
 int rtmi_scene_file_info(const rtmi_scene_file *, uint64_t *n_tris, uint32_t *n_objects, uint32_t *n_lights);
 int rtmi_scene_file_get(const rtmi_scene_file *, double *tri_xyz, uint32_t *tri_object, double *tri_normals,

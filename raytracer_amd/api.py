@@ -80,7 +80,7 @@ SYMBOLS = [
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev", "rtmi_radiosity_solve_noalloc_dev",
     "rtmi_shader_create", "rtmi_shader_destroy", "rtmi_trace_dev", "rtmi_render_frame_dev", "rtmi_tone_map_dev",
     "rtmi_raster_setup", "rtmi_render_frame_sampled_dev", "rtmi_soft_shadow_rays_dev", "rtmi_soft_shadow_factor_dev", "rtmi_soft_shadow_dev",
-    "rtmi_scene_file_load", "rtmi_scene_file_free", "rtmi_scene_file_info", "rtmi_scene_file_get",
+    "rtmi_scene_file_load", "rtmi_scene_file_load_ex", "rtmi_scene_file_free", "rtmi_scene_file_info", "rtmi_scene_file_get",
     "rtmi_radiosity_trace_dev", "rtmi_radiosity_raster_dev", "rtmi_tone_map_radiosity_dev",
 ]
 
@@ -148,6 +148,8 @@ def _load():
     L.rtmi_tone_map_radiosity_dev.argtypes = [vp, u64, vp, vp]
     L.rtmi_scene_file_load.restype = vp
     L.rtmi_scene_file_load.argtypes = [C.c_char_p, C.c_char_p]
+    L.rtmi_scene_file_load_ex.restype = vp
+    L.rtmi_scene_file_load_ex.argtypes = [C.c_char_p, C.c_char_p, u32]
     L.rtmi_scene_file_free.argtypes = [vp]
     L.rtmi_scene_file_free.restype = None
     L.rtmi_scene_file_info.argtypes = [vp, vp, vp, vp]
@@ -205,10 +207,14 @@ def check_hierarchy(tri_xyz):
     return tuple(int(v) for v in stats)
 
 
-def BuildScene(scenes_dir, stem):
+SCENE_LENIENT = 1
+
+
+def BuildScene(scenes_dir, stem, lenient=False):
     """bool Scene::BuildScene(file, fileObj, camera) (scene.cpp:209-460): reads <scenes_dir>/<stem>.sdf and its .obj files
-    (host only).  Returns a dict: tris n x 9, tri_obj n, normals n x 3, mats n_obj x 18, lights n_l x 6, cam14, res."""
-    h = lib.rtmi_scene_file_load(str(scenes_dir).encode(), str(stem).encode())
+    (host only).  Returns a dict: tris n x 9, tri_obj n, normals n x 3, mats n_obj x 18, lights n_l x 6, cam14, res.
+    lenient: without the reference's limits (512-byte lines, `o <name>` first, triangles and quads only)."""
+    h = lib.rtmi_scene_file_load_ex(str(scenes_dir).encode(), str(stem).encode(), SCENE_LENIENT if lenient else 0)
     if not h:
         raise RtmiError(lib.rtmi_last_error().decode())
     h = C.c_void_p(h)

@@ -192,6 +192,35 @@ def test_scene_file_reader_errors(tmp_path):
         rt.BuildScene(str(tmp_path), "b")
 
 
+def test_lenient_reader_takes_what_the_references_reader_cannot(tmp_path):
+    """the reference's reader stops at 512-byte lines (scene.cpp:211), wants `o <file name>` first
+    (:400-405) and splits triangles and quads only (params.cpp:214).  tools/gen_obj.py writes a mesh that breaks all three
+    (plus relative indices, a//c corners, groups); RTMI_SCENE_LENIENT reads it to exactly the triangles it stands for, the
+    default mode treats it as the reference does: the object stays empty."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_obj
+    import raytracer_amd as rt
+    want = gen_obj.generate(str(tmp_path), "terrain", 12)
+    strict = rt.BuildScene(str(tmp_path), "terrain")
+    assert len(strict["tris"]) == 0 and len(strict["mats"]) == 1                      # name mismatch: the file is dropped
+    got = rt.BuildScene(str(tmp_path), "terrain", lenient=True)
+    assert np.array_equal(got["tris"], want) and len(want) > 12 * 12 * 2
+    assert np.all(got["tri_obj"] == 0) and got["lights"].shape == (1, 6) and tuple(got["res"]) == (960, 540)
+    n = got["normals"]
+    assert np.allclose((n * n).sum(1), 1.0) and (n[:, 2] > 0).mean() > 0.95          # unit normals, the terrain faces up
+    # a strict-conforming file reads the same in both modes
+    (tmp_path / "plain.sdf").write_text("object plain\n")
+    (tmp_path / "plain.obj").write_text("o plain\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\nf 1 2 3\n")
+    a, b = rt.BuildScene(str(tmp_path), "plain"), rt.BuildScene(str(tmp_path), "plain", lenient=True)
+    assert len(a["tris"]) == 3 and np.array_equal(a["tris"], b["tris"]) and np.array_equal(a["normals"], b["normals"])
+    # five corners: the reference keeps the first triangle only, lenient mode fans on
+    (tmp_path / "plain.obj").write_text("o plain\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0.5 1.5 0\nv 0 1 0\nf 1 2 3 4 5\n")
+    assert len(rt.BuildScene(str(tmp_path), "plain")["tris"]) == 1 and len(rt.BuildScene(str(tmp_path), "plain", lenient=True)["tris"]) == 3
+    with pytest.raises(rt.RtmiError, match="could not open"):
+        (tmp_path / "gone.sdf").write_text("object not_there\n")
+        rt.BuildScene(str(tmp_path), "gone", lenient=True)
+
+
 @pytest.mark.parametrize("case", ["n1", "n2", "n3", "n5", "n64", "soup20k", "offset", "flat", "mixed_scales", "grid", "duplicates"])
 def test_hierarchy_invariants_on_the_host(case):
     """rtmi_debug_check_hierarchy (host only): the binary + 4-wide hierarchies rtmi_scene_create builds keep every
