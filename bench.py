@@ -249,9 +249,22 @@ def main():
             if rc != 0:
                 raise SystemExit(rt.lib.rtmi_last_error().decode())
             sweeps, rel = stats.sweeps, stats.rel_change
+            solve_path = "rtmi_radiosity_solve_dev"
+        elif backend == "nccl":
+            # the sharded loop inside the library: sweep kernel + RCCL all-gather enqueued back to back, host waits at the checks
+            try:
+                B, stats = multi.solve_sharded_library(F.data_ptr(), ld, n, row0, n_rows, rho, E, tol_rel=1e-4, max_sweeps=1000, check_every=4, stream=stream)
+                sweeps, rel = stats.sweeps, stats.rel_change
+                solve_path = "rtmi_radiosity_solve_sharded_dev (RCCL inside the library)"
+            except rt.RtmiError as e:     # e.g. no librccl for dlopen: the Python loop over torch.distributed does the same iteration
+                print("bench.py: library exchange unavailable (%s): falling back to multi.solve_sharded" % e, file=sys.stderr, flush=True)
+                r = multi.solve_sharded(sweep, E, n, tol_rel=1e-4, max_sweeps=1000, check_every=4)
+                B, sweeps, rel = r.B, r.sweeps, r.rel_change
+                solve_path = "multi.solve_sharded (torch.distributed)"
         else:
             r = multi.solve_sharded(sweep, E, n, tol_rel=1e-4, max_sweeps=1000, check_every=4)
             B, sweeps, rel = r.B, r.sweeps, r.rel_change
+            solve_path = "multi.solve_sharded (torch.distributed, %s)" % backend
         barrier()
         solve_s = max_over_ranks(time.perf_counter() - t0)
         # residual of the solution: one more sweep must not move it
@@ -261,7 +274,7 @@ def main():
         torch.cuda.synchronize()
         solver = {"patches": n, "F": "synthetic uniform(0,1), zero diagonal, row sums 0.9, fp32, %.2f GiB/rank" % (n_rows * ld * 4 / 2**30),
                   "scaling": "strong (rows sharded over ranks, RCCL all-gather of B per sweep)" if world > 1 else "single GPU",
-                  "sweeps": int(sweeps), "rel_change": rel, "solve_seconds": round(solve_s, 5),
+                  "path": solve_path, "sweeps": int(sweeps), "rel_change": rel, "solve_seconds": round(solve_s, 5),
                   "ms_per_sweep_kernel": round(sweep_ms, 4), "ms_per_sweep_in_solve": round(solve_s * 1e3 / max(1, sweeps), 4)}
         del F
         torch.cuda.empty_cache()

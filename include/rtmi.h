@@ -334,6 +334,26 @@ int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t
                              uint32_t check_every, rtmi_exchange_fn exchange, void *user, rtmi_solve_stats *stats,
                              void *stream);
 
+/* The same solve across GPUs, the exchange INSIDE the library (RCCL over xGMI): for hosts that are not Python — the
+ * reference's driver is a C++ program (Render2/main.cpp:6-49).  No reference counterpart (its solver is one thread).
+ * One process (or thread) per GPU; F is row-sharded in equal blocks: with blk = ceil(n / world), rank r owns rows
+ * [min(n, r·blk), min(n, (r+1)·blk)) — pass them as row0 / n_rows, with d_F pointing at the rank's first row.
+ *   rtmi_comm_unique_id   rank 0 draws an id (ncclGetUniqueId) and hands it to the other ranks by its own means
+ *   rtmi_comm_create      every rank, on its own GPU (the current device), with the same id: collective
+ *   rtmi_radiosity_solve_sharded_dev   collective: every rank calls it with the same n, tolerances and check_every.
+ *     Per sweep: the sweep kernel on this rank's rows, then an in-place all-gather of the ranks' blocks of B — both only
+ *     enqueued on `stream`; every check_every sweeps two small all-reduces of the norms and ONE host wait.  d_B [n][3]
+ *     receives all rows on every rank; stats->seconds is host wall time (sweeps, exchange and checks).
+ * RCCL is loaded at run time (dlopen librccl.so.1); without it these three fail with a message, nothing else needs it. */
+#define RTMI_COMM_ID_BYTES 128
+typedef struct rtmi_comm rtmi_comm;
+int rtmi_comm_unique_id(uint8_t id[RTMI_COMM_ID_BYTES]);
+rtmi_comm *rtmi_comm_create(const uint8_t id[RTMI_COMM_ID_BYTES], int rank, int world);
+void rtmi_comm_destroy(rtmi_comm *);
+int rtmi_radiosity_solve_sharded_dev(rtmi_comm *, const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows,
+                                     const double rho[3], const float *d_E, float *d_B, float tol_rel, uint32_t max_sweeps,
+                                     uint32_t check_every, rtmi_solve_stats *stats, void *stream);
+
 /* The same solve for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for hosts that must not
  * call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  It is
  * rtmi_radiosity_solve_dev with exchange = NULL over all n rows (same kernels, same results bit for bit), but the solver's

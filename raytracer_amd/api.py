@@ -78,6 +78,7 @@ SYMBOLS = [
     "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev", "rtmi_shadow_occlusion_dev", "rtmi_debug_check_hierarchy",
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev", "rtmi_radiosity_solve_noalloc_dev",
+    "rtmi_comm_unique_id", "rtmi_comm_create", "rtmi_comm_destroy", "rtmi_radiosity_solve_sharded_dev",
     "rtmi_shader_create", "rtmi_shader_destroy", "rtmi_trace_dev", "rtmi_render_frame_dev", "rtmi_tone_map_dev",
     "rtmi_raster_setup", "rtmi_render_frame_sampled_dev", "rtmi_soft_shadow_rays_dev", "rtmi_soft_shadow_factor_dev", "rtmi_soft_shadow_dev",
     "rtmi_scene_file_load", "rtmi_scene_file_load_ex", "rtmi_scene_file_free", "rtmi_scene_file_info", "rtmi_scene_file_get",
@@ -132,6 +133,12 @@ def _load():
     L.rtmi_radiosity_solve_dev.argtypes = [vp, u64, u32, u32, u32, vp, vp, vp, C.c_float, u32, u32, vp, vp,
                                            C.POINTER(rtmi_solve_stats), vp]
     L.rtmi_radiosity_solve_noalloc_dev.argtypes = [vp, u64, u32, vp, vp, vp, C.c_float, u32, u32, C.POINTER(rtmi_solve_stats), vp]
+    L.rtmi_comm_unique_id.argtypes = [vp]
+    L.rtmi_comm_create.restype = vp
+    L.rtmi_comm_create.argtypes = [vp, C.c_int, C.c_int]
+    L.rtmi_comm_destroy.argtypes = [vp]
+    L.rtmi_comm_destroy.restype = None
+    L.rtmi_radiosity_solve_sharded_dev.argtypes = [vp, vp, u64, u32, u32, u32, vp, vp, vp, C.c_float, u32, u32, C.POINTER(rtmi_solve_stats), vp]
     L.rtmi_shader_create.restype = vp
     L.rtmi_shader_create.argtypes = [vp, vp, vp, u32, vp, u32]
     L.rtmi_shader_destroy.argtypes = [vp]
@@ -534,7 +541,13 @@ class Radiosity:
         dE = torch.from_numpy(E).cuda()
         st = torch.cuda.current_stream().cuda_stream
         stats = rtmi_solve_stats()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if (sharded and dist.get_backend() == "nccl") or os.environ.get("RTMI_SOLVE_IN_LIBRARY") == "1":
+            # production: the loop and its RCCL exchange run inside the library (a communicator of one rank works too)
+            from . import multi
+            self.B, stats = multi.solve_sharded_library(self.FF.data_ptr(), self.ld, self.n, self.row0, self.n_rows, rho, dE, tol_rel,
+                                                        max_sweeps, check_every, stream=st)
+        elif sharded:
             from . import multi
             row0, n_rows = self.row0, self.n_rows
 

@@ -68,6 +68,11 @@ __device__ __forceinline__ D3 sample_point(const double *__restrict__ e, uint64_
 	return sample_point_h(e, mix64(seed ^ (((uint64_t)a << 32) | b)), k, which);
 }
 
+constexpr uint32_t kNormSlots = 64; // k_jacobi_sweep spreads its norm atomics over this many triples
+// one Jacobi sweep (rtmi_radiosity.hip); block b adds its norms to triple b % slots of d_norms
+int sweep_launch_slots(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3], const float *d_E,
+                       const float *d_B_old, float *d_B_new, double *d_norms, uint32_t slots, void *stream);
+
 inline int check_patches(const rtmi_patches *p, const char *who) {
 	if (!p) return fail(std::string(who) + ": patches is NULL");
 	int dev = -1;

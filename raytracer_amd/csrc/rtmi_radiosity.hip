@@ -37,7 +37,6 @@ RTMI_TRAVERSAL_KERNEL void k_visible_points(SceneDev S, PatchesDev P, uint64_t m
 #ifndef RTMI_JBLOCK
 #define RTMI_JBLOCK 256
 #endif
-constexpr uint32_t kNormSlots = 64;
 constexpr int kRows = RTMI_JROWS;
 constexpr int kJBlock = RTMI_JBLOCK, kJWaves = RTMI_JBLOCK / 64;
 static_assert(kRows * 3 <= 32, "the final reduction runs over the first 32 lanes of wave 0");
@@ -462,6 +461,23 @@ static unsigned char *scratch_of_current_device(const char *who) {
 
 using namespace rtmi;
 
+// One sweep; the three norms are accumulated into `slots` triples (block b into triple b % slots), which the caller adds up.
+int rtmi::sweep_launch_slots(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3],
+                        const float *d_E, const float *d_B_old, float *d_B_new, double *d_norms, uint32_t slots, void *stream) {
+	const char *who = "rtmi_jacobi_sweep_dev";
+	if (n_rows == 0) return 0;
+	if (!d_F || !rho || !d_E || !d_B_old || !d_B_new || !d_norms) return fail(std::string(who) + ": NULL argument");
+	if ((uint64_t)row0 + n_rows > n) return fail(std::string(who) + ": row range exceeds n");
+	if (ld < n) return fail(std::string(who) + ": ld < n");
+	if ((ld & 3u) || ((uintptr_t)d_F & 15u) || ((uintptr_t)d_B_old & 15u))
+		return fail(std::string(who) + ": d_F / d_B_old must be 16-byte aligned and ld a multiple of 4");
+	if (d_B_old == d_B_new) return fail(std::string(who) + ": Jacobi needs distinct B_old and B_new");
+	const uint32_t grid = (n_rows + kRows - 1) / kRows;
+	hipLaunchKernelGGL(k_jacobi_sweep, dim3(grid), dim3(kJBlock), 0, (hipStream_t)stream, d_F, ld, n, row0, n_rows, rho[0], rho[1],
+	                   rho[2], d_E, d_B_old, d_B_new, d_norms, slots);
+	return launch_check(who);
+}
+
 extern "C" {
 
 static rtmi_patches *patches_create(rtmi_scene *s, const double *verts, const double *normals);
@@ -562,26 +578,9 @@ int rtmi_visible_points(rtmi_patches *P, uint64_t m, const int32_t *ej, const do
 	return rc;
 }
 
-// One sweep; the three norms are accumulated into `slots` triples (block b into triple b % slots), which the caller adds up.
-static int sweep_launch(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3],
-                        const float *d_E, const float *d_B_old, float *d_B_new, double *d_norms, uint32_t slots, void *stream) {
-	const char *who = "rtmi_jacobi_sweep_dev";
-	if (n_rows == 0) return 0;
-	if (!d_F || !rho || !d_E || !d_B_old || !d_B_new || !d_norms) return fail(std::string(who) + ": NULL argument");
-	if ((uint64_t)row0 + n_rows > n) return fail(std::string(who) + ": row range exceeds n");
-	if (ld < n) return fail(std::string(who) + ": ld < n");
-	if ((ld & 3u) || ((uintptr_t)d_F & 15u) || ((uintptr_t)d_B_old & 15u))
-		return fail(std::string(who) + ": d_F / d_B_old must be 16-byte aligned and ld a multiple of 4");
-	if (d_B_old == d_B_new) return fail(std::string(who) + ": Jacobi needs distinct B_old and B_new");
-	const uint32_t grid = (n_rows + kRows - 1) / kRows;
-	hipLaunchKernelGGL(k_jacobi_sweep, dim3(grid), dim3(kJBlock), 0, (hipStream_t)stream, d_F, ld, n, row0, n_rows, rho[0], rho[1],
-	                   rho[2], d_E, d_B_old, d_B_new, d_norms, slots);
-	return launch_check(who);
-}
-
 int rtmi_jacobi_sweep_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3],
                           const float *d_E, const float *d_B_old, float *d_B_new, double *d_norms, void *stream) {
-	return sweep_launch(d_F, ld, n, row0, n_rows, rho, d_E, d_B_old, d_B_new, d_norms, 1, stream);
+	return sweep_launch_slots(d_F, ld, n, row0, n_rows, rho, d_E, d_B_old, d_B_new, d_norms, 1, stream);
 }
 
 // The Jacobi loop shared by rtmi_radiosity_solve_dev (which allocates d_tmp / d_norms per call) and
@@ -606,7 +605,7 @@ static int solve_loop(const char *who, const float *d_F, uint64_t ld, uint32_t n
 	auto window = [&](uint32_t k, int from, hipStream_t s) -> int {
 		if (hipMemsetAsync(d_norms, 0, nb * k, s) != hipSuccess) return fail(std::string(who) + ": memset failed");
 		for (uint32_t i = 0; i < k; ++i) {
-			if (sweep_launch(d_F, ld, n, row0, n_rows, rho, d_E, buf[(from + i) & 1], buf[(from + i + 1) & 1], d_norms + 3 * slots * i, slots, s)) return -1;
+			if (sweep_launch_slots(d_F, ld, n, row0, n_rows, rho, d_E, buf[(from + i) & 1], buf[(from + i + 1) & 1], d_norms + 3 * slots * i, slots, s)) return -1;
 			if (exchange && exchange(user, buf[(from + i + 1) & 1], d_norms + 3 * slots * i, s) != 0) return fail(std::string(who) + ": exchange callback failed");
 		}
 		return 0;

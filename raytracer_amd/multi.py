@@ -5,12 +5,61 @@
   * form factors: rank r owns rows rows_of_rank(n, r, W) of F — no collective.
   * whole frames: each rank renders its tiles into a zeroed full-size buffer; render_frame_sharded() assembles the image
     on every rank with ONE all-reduce (sum: every pixel is written by exactly one rank).
-  * solve: F stays row-sharded; after each Jacobi sweep the ranks all-gather their rows of B
-    (RCCL over xGMI on the GPU box, gloo in the CPU tests) and all-reduce the three norms.
+  * solve: F stays row-sharded; after each Jacobi sweep the ranks all-gather their rows of B and, at every convergence
+    check, all-reduce the three norms.  In production that loop runs INSIDE the library (rtmi_radiosity_solve_sharded_dev:
+    sweep kernel and RCCL all-gather enqueued back to back on one stream, the host waits only at the checks) —
+    solve_sharded_library() below only hands it the communicator id; solve_sharded() is the same iteration driven from
+    Python over torch.distributed (gloo in the CPU tests, a rehearsal path on the GPU box).
 
-Nothing here computes: the sweep itself is passed in (the HIP kernel through the C ABI in production).
+Nothing here computes: the sweep itself is the HIP kernel behind the C ABI.
 """
+import ctypes as C
 import math
+
+_COMMS = {}
+
+
+def library_comm(group=None):
+    """The library's own RCCL communicator (rtmi_comm) over the ranks of `group`: rank 0 draws the id, torch.distributed
+    carries it to the others, every rank joins on its current GPU.  One per (process, group); world size 1 needs no
+    torch.distributed at all."""
+    import torch.distributed as dist
+    from . import api
+    live = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if live else 1
+    rank = dist.get_rank(group) if live else 0
+    key = (id(group), world, rank)
+    if key in _COMMS:
+        return _COMMS[key]
+    ident = (C.c_uint8 * 128)()
+    if rank == 0:
+        api._check(api.lib.rtmi_comm_unique_id(ident))
+    if world > 1:
+        box = [bytes(ident) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+    h = api.lib.rtmi_comm_create(ident, rank, world)
+    if not h:
+        raise api.RtmiError(api.lib.rtmi_last_error().decode())
+    _COMMS[key] = (C.c_void_p(h), rank, world)
+    return _COMMS[key]
+
+
+def solve_sharded_library(d_F, ld, n, row0, n_rows, rho, E, tol_rel=1e-7, max_sweeps=1000, check_every=4, group=None, stream=None):
+    """rtmi_radiosity_solve_sharded_dev: the whole sharded Jacobi loop inside the library, exchange over RCCL.  d_F: device
+    pointer of this rank's first row; rows [row0, row0 + n_rows) must be rows_of_rank(n, rank, world).  Returns
+    (B [n, 3] on the device, rtmi_solve_stats)."""
+    import numpy as np
+    import torch
+    from . import api
+    comm, rank, world = library_comm(group)
+    rho = np.ascontiguousarray(rho, np.float64)
+    B = torch.zeros((n, 3), dtype=torch.float32, device=E.device)
+    stats = api.rtmi_solve_stats()
+    st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    api._check(api.lib.rtmi_radiosity_solve_sharded_dev(comm, d_F, ld, n, row0, n_rows, rho.ctypes.data, E.data_ptr(), B.data_ptr(), tol_rel,
+                                                        max_sweeps, check_every, C.byref(stats), st))
+    return B, stats
 
 
 def rows_of_rank(n, rank, world):

@@ -481,6 +481,50 @@ def test_jacobi_sweep_vs_oracle_rgb(rt, oracle, n):
     assert 5 < stats.sweeps < 500 and stats.rel_change <= 1e-7
 
 
+def test_sharded_solve_inside_the_library_one_rank(rt, monkeypatch):
+    """rtmi_radiosity_solve_sharded_dev with a communicator of ONE rank (RCCL loaded at run time): the exchange path —
+    in-place all-gather per sweep, all-reduced norms per check — on hardware.  A fixed number of sweeps gives the bits of
+    rtmi_radiosity_solve_dev (same kernel launches); to tolerance the same sweep count and B; Radiosity.progressiveRefinement
+    takes that path with RTMI_SOLVE_IN_LIBRARY=1; and the Python loop multi.solve_sharded drives the real sweep too."""
+    import torch
+    from raytracer_amd import multi
+    n = 777
+    rng = np.random.default_rng(9)
+    F = rng.random((n, n)).astype(np.float32)
+    np.fill_diagonal(F, 0)
+    F *= (0.9 / F.sum(1))[:, None].astype(np.float32)
+    ld = (n + 3) // 4 * 4
+    Fp = np.zeros((n, ld), np.float32); Fp[:, :n] = F
+    rho = np.array([0.84, 0.37, 0.7])
+    E = (rng.random((n, 3)) * 100).astype(np.float32)
+    dF = torch.from_numpy(Fp).cuda(); dE = torch.from_numpy(E).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for tol, sweeps_max, ce in ((0.0, 21, 4), (1e-6, 500, 3)):
+        ref = torch.zeros_like(dE)
+        s0 = rt.api.radiosity_solve_dev(dF.data_ptr(), ld, n, rho, dE.data_ptr(), ref.data_ptr(), tol, sweeps_max, ce, st)
+        B, s1 = multi.solve_sharded_library(dF.data_ptr(), ld, n, 0, n, rho, dE, tol_rel=tol, max_sweeps=sweeps_max, check_every=ce)
+        torch.cuda.synchronize()
+        assert s0.sweeps == s1.sweeps and np.array_equal(B.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
+        assert s1.max_change == s0.max_change and abs(s1.rel_change - s0.rel_change) <= 1e-12 * max(s0.rel_change, 1e-300)
+    # the Python loop over the same sweep (a group of one): the callback path on hardware
+    def sweep(B_old, B_new, norms):
+        rt.jacobi_sweep_dev(dF.data_ptr(), ld, n, 0, n, rho, dE.data_ptr(), B_old.data_ptr(), B_new.data_ptr(), norms.data_ptr(), st)
+    r = multi.solve_sharded(sweep, dE, n, tol_rel=1e-6, max_sweeps=500, check_every=3)
+    assert r.sweeps == s1.sweeps and np.array_equal(r.B.cpu().numpy(), B.cpu().numpy())
+    # a row range that is not the rank's block is refused when there is more than one rank; with one rank any range runs
+    B2, s2 = multi.solve_sharded_library(dF.data_ptr(), ld, n, 0, 100, rho, dE, tol_rel=0.0, max_sweeps=2, check_every=1)
+    assert s2.sweeps == 2
+    # the member-function mirror
+    g = load_golden("g4_practice_room_enclosed.npz")
+    rad = rt.Radiosity(rt.Scene(g["verts"]), g["normals"], g["light_center"])
+    rad.findFormFactor(samples=int(g["S"]), light_samples=int(g["SL"]), seed=int(g["seed"]))
+    rad.progressiveRefinement(tol_rel=1e-7)
+    Bplain = rad.B.cpu().numpy().copy()
+    monkeypatch.setenv("RTMI_SOLVE_IN_LIBRARY", "1")
+    rad.progressiveRefinement(tol_rel=1e-7)
+    assert np.array_equal(rad.B.cpu().numpy(), Bplain)
+
+
 def test_jacobi_argument_errors(rt):
     import torch
     x = torch.zeros(64, device="cuda")
