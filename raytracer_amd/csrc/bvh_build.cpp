@@ -251,13 +251,30 @@ int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err, unsigned n_threads
 	struct Plan { uint32_t build_id; int32_t kid[4]; uint32_t nk, ni, inner_base, tri_base; };
 	std::vector<Plan> plan;
 	plan.reserve(bvh.nodes.size() / 3 + 1);
-	struct Item { uint32_t build_id, out_id; };
-	std::vector<Item> todo;
+	// Order: the root, its inner children and THEIR inner children take the first slots, level by level (out.n_top of
+	// them: the kernels may keep those in LDS); below that depth-first, a node's first child laid out right behind it.
+	struct Item { uint32_t build_id, out_id, level; };
+	std::vector<Item> todo, later;
+	size_t head = 0;
 	plan.emplace_back();
-	todo.push_back({0u, 0u});
-	while (!todo.empty()) {
-		const Item it = todo.back();
-		todo.pop_back();
+	todo.push_back({0u, 0u, 0u});
+	bool top_phase = true;
+	out.n_top = 1;
+	while (true) {
+		Item it;
+		if (top_phase) {
+			if (head == todo.size()) { // the two top levels are laid out: the rest goes depth-first
+				top_phase = false;
+				out.n_top = (uint32_t)plan.size();
+				todo.assign(later.rbegin(), later.rend());
+				continue;
+			}
+			it = todo[head++];
+		} else {
+			if (todo.empty()) break;
+			it = todo.back();
+			todo.pop_back();
+		}
 		const BuildNode &x = bvh.nodes[it.build_id];
 		Plan p;
 		p.build_id = it.build_id;
@@ -280,7 +297,11 @@ int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err, unsigned n_threads
 		p.inner_base = (uint32_t)plan.size();
 		p.tri_base = next_tri;
 		for (int k = 0; k < ni; ++k) plan.emplace_back();
-		for (int k = ni - 1; k >= 0; --k) todo.push_back({(uint32_t)p.kid[k], p.inner_base + (uint32_t)k}); // child 0 is laid out next
+		if (top_phase) {
+			for (int k = 0; k < ni; ++k) (it.level < 1 ? todo : later).push_back({(uint32_t)p.kid[k], p.inner_base + (uint32_t)k, it.level + 1u});
+		} else {
+			for (int k = ni - 1; k >= 0; --k) todo.push_back({(uint32_t)p.kid[k], p.inner_base + (uint32_t)k, it.level + 1u}); // child 0 is laid out next
+		}
 		for (int k = ni; k < nk; ++k) {
 			if (bvh.nodes[p.kid[k]].count != 1) { err = "a leaf with more than one triangle"; return -1; }
 			out.leaf_pos[p.kid[k]] = next_tri++;

@@ -41,6 +41,7 @@ struct Wide4 {
 	std::vector<uint32_t> leaf_pos; // per binary build node: position of a leaf's triangle in the device's triangle array
 	std::vector<uint32_t> build_of; // per wide node: the binary inner node it stands for
 	uint32_t stack_need = 0;        // entries the deepest root-to-leaf path can leave on the traversal stack
+	uint32_t n_top = 0;             // nodes[0 .. n_top) are the root, its inner children and their inner children (<= 21)
 };
 // Collapses a binary hierarchy whose leaves hold ONE triangle each.  Returns 0, or -1 with a message.
 int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err, unsigned n_threads = 1);

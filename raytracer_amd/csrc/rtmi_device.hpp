@@ -60,9 +60,13 @@ constexpr uint32_t kQueueChunk = 256;     // items a wave takes from the launch'
 #endif
 constexpr uint32_t kTailChunk = RTMI_TAIL_CHUNK; // ... and once the queue is down to its last chunk per resident wave (see trace_queue)
 constexpr int kLeaf = INT32_MIN + 1;      // lane state: working through the triangles of a leaf
+#ifndef RTMI_TOP_LDS
+#define RTMI_TOP_LDS 0
+#endif
+constexpr uint32_t kTopNodes = 21;        // root + 4 + 16: the levels trace_queue can keep in LDS (RTMI_TOP_LDS=1; measured)
 // Traversal kernels are latency-bound: ask the register allocator for at least this many waves per SIMD.
 #ifndef RTMI_WAVES
-#define RTMI_WAVES 6
+#define RTMI_WAVES 5
 #endif
 #define RTMI_TRAVERSAL_KERNEL_W(w) __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(w, 8)))
 #define RTMI_TRAVERSAL_KERNEL RTMI_TRAVERSAL_KERNEL_W(RTMI_WAVES)
@@ -75,6 +79,7 @@ struct SceneDev {
 	const GTri *tris;
 	int32_t root_ref; // kSentinel for an empty scene
 	float absmax;     // max |coordinate| of the scene bounds (for the per-ray box padding)
+	uint32_t n_top;   // wnodes[0 .. n_top) = the top three levels of the 4-wide hierarchy (<= kTopNodes): staged in LDS by trace_queue
 	uint32_t guard;   // wave-iterations a traversal may spend on one ray (kGuard; RTMI_GUARD overrides it, tests)
 	int *error;       // host-mapped word, set to 1 when a wave gives up: the host entries report it (rtmi_scene_check)
 };
@@ -228,9 +233,15 @@ __device__ __forceinline__ int sbyte(uint32_t w, int k) { return (int)(w << (24 
 // (farthest first), or pop.  Returns the lane's next reference (inner node, raw leaf reference, or kSentinel).
 // A hit child is carried as ONE sortable word: the bits of its entry distance (>= 0, so they order like the float) with
 // the child's number in the two lowest bits; 0xffffffff = not hit.  Five min/max pairs sort the four words.
-__device__ __forceinline__ int node_step(const SceneDev &S, const RayW &r, float tbest, int cur, int &sp, int *stack) {
+__device__ __forceinline__ int node_step(const SceneDev &S, const RayW &r, float tbest, int cur, int &sp, int *stack, const WNode *top = nullptr,
+                                         uint32_t n_top = 0) {
 	const WNode *np = S.wnodes + cur;
-	const uint4 a = np->a, b = np->b, c = np->c;
+	uint4 a, b, c;
+#if RTMI_TOP_LDS
+	if ((uint32_t)cur < n_top) { a = top[cur].a; b = top[cur].b; c = top[cur].c; } // the levels every ray starts in: from LDS
+	else
+#endif
+	{ a = np->a; b = np->b; c = np->c; }
 	const float ax = ldexpf(r.ix, sbyte(a.w, 0)), ay = ldexpf(r.iy, sbyte(a.w, 1)), az = ldexpf(r.iz, sbyte(a.w, 2));
 	const float px = __uint_as_float(a.x), py = __uint_as_float(a.y), pz = __uint_as_float(a.z);
 	const float bnx = fmaf(px, r.ix, r.cnx), bny = fmaf(py, r.iy, r.cny), bnz = fmaf(pz, r.iz, r.cnz);
@@ -359,7 +370,7 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 
 // ---------------------------------------------------------------- persistent waves over a work queue
 // refill threshold and phase-vote weights of trace_queue (RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF override)
-struct Tune { int thresh, vote_node, vote_leaf; };
+struct Tune { int thresh, vote_node, vote_leaf; uint32_t chunk, tail_chunk; }; // chunk: items per claim (kQueueChunk unless the launch is small)
 
 // The launch owns `n_items` work items (rays) and ONE counter in device memory (zeroed on the stream before the
 // kernel); its grid is persistent — as many workgroups as the device holds at once.  Every lane traces one ray at
@@ -380,10 +391,19 @@ struct HitQ { double t; float u, v; uint32_t pos; }; // pos == RTMI_MISS: no hit
 // UNIFORM_O: every ray of the launch starts at (uox, uoy, uoz) (primary rays: the eye) — the origin then
 // lives in scalar registers instead of six VGPRs per lane; fetch() need not fill R.ox..oz.
 template <bool ANY, bool COUNT, bool UNIFORM_O, class Fetch, class Emit>
-__device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *counter, uint32_t n_items, int thresh,
-                                            int vote_node, int vote_leaf, double uox, double uoy, double uoz, Fetch fetch,
-                                            Emit emit, Work *w = nullptr) {
+__device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *counter, uint32_t n_items, const Tune &tune,
+                                            double uox, double uoy, double uoz, Fetch fetch, Emit emit, Work *w = nullptr) {
+	const int thresh = tune.thresh, vote_node = tune.vote_node, vote_leaf = tune.vote_leaf;
 	const uint32_t lane = threadIdx.x & 63u;
+#if RTMI_TOP_LDS
+	__shared__ WNode top[kTopNodes];
+	const uint32_t n_top = min(S.n_top, kTopNodes);
+	if (threadIdx.x < 3u * n_top) reinterpret_cast<uint4 *>(top)[threadIdx.x] = reinterpret_cast<const uint4 *>(S.wnodes)[threadIdx.x];
+	__syncthreads();
+#else
+	const WNode *top = nullptr;
+	const uint32_t n_top = 0;
+#endif
 	RayD R = {0, 0, 0, 0, 0, 1, 0};
 	RayW r = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	HitQ h = {0.0, 0.f, 0.f, RTMI_MISS};
@@ -399,7 +419,12 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 	// chunk's worth of rays per lane (4 rays of ≈ 90 µs on the C3 soup: 12 % of the 4K frame, half of a million-ray launch).
 	// Once fewer items are left than one full chunk per resident wave, claims are therefore smaller (the wave judges that from
 	// the counter value its previous claim returned); all other claims stay large to keep the atomics on the counter rare.
-	const uint32_t tail_window = gridDim.x * (kBlock / 64u) * kQueueChunk;
+	// The claim size adapts to what the rays cost (wave-uniform): claims are atomics on ONE counter, which serialise at about
+	// 8 ns each, so a wave should not claim more often than every few dozen iterations — cheap rays (a room's primary rays,
+	// short any-hit rays) keep large claims; rays that take hundreds of steps (the 1 Mi-triangle soup) come down to 64-item
+	// claims, one 8 x 8 pixel square, which balances the waves better (C3: 2.84 ms with 256-item claims, 2.59 ms adaptive).
+	uint32_t cur_chunk = tune.chunk, since_claim = 0;
+	const uint32_t resident_waves = gridDim.x * (kBlock / 64u);
 	uint32_t seen = 0; // the counter as of this wave's last claim
 	uint32_t guard = 0;
 	auto start = [&]() { // R holds a new ray: reset the lane's traversal state
@@ -437,7 +462,11 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 					if (left < nidle && global_more) {
 						const uint32_t leader = (uint32_t)(__ffsll((long long)idle) - 1);
 						uint32_t base = 0;
-						const uint32_t chunk = (seen < n_items && n_items - seen > tail_window) ? kQueueChunk : kTailChunk;
+						if (since_claim > 128u && cur_chunk > 64u) cur_chunk >>= 1;
+						else if (since_claim < 40u && cur_chunk < tune.chunk) cur_chunk <<= 1;
+						since_claim = 0;
+						// once fewer items are left than one claim per resident wave, claims are halved (see above)
+						const uint32_t chunk = (seen < n_items && n_items - seen > resident_waves * cur_chunk) ? cur_chunk : max(tune.tail_chunk, cur_chunk >> 1);
 						if (lane == leader) base = (uint32_t)atomicAdd(counter, (int)chunk);
 						fresh = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
 						seen = fresh;
@@ -479,6 +508,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 			cur = kLeaf;
 		}
 		if (++guard > S.guard) { give_up(S); break; } // a wave that cannot finish must still end: never reached on valid input
+		++since_claim;
 		// Vote: the wave runs ONE node step or ONE triangle step per iteration, whichever has more lanes
 		// waiting (a triangle step costs about twice a node step).  Lanes of the other kind simply wait, so
 		// no lane ever runs ahead speculatively and the visited set is exactly the sequential one.
@@ -497,7 +527,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 				}
 				if (cur >= 0) {
 					if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
-					cur = node_step(S, r, tbest, cur, sp, stack);
+					cur = node_step(S, r, tbest, cur, sp, stack, top, n_top);
 				}
 			}
 		} else {

@@ -46,6 +46,7 @@ int fail(const std::string &msg);        // records msg for rtmi_last_error(), r
 int launch_check(const char *who);
 int check_scene(const rtmi_scene *s, const char *who); // NULL / wrong current device -> -1
 unsigned env_uint(const char *name, unsigned dflt); // tuning overrides from the environment
+Tune launch_tune(Tune t, uint32_t grid, uint64_t n_items); // claim sizes for a launch of n_items on `grid` persistent workgroups
 Tune refill_threshold();                          // RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF, read once per process
 // ray queries whose ray count lives on the device: min(cap, *d_n · mul) rays of the buffer are traced
 int closest_hit_counted(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t cap, const uint32_t *d_n, uint32_t mul, rtmi_hit *d_out,

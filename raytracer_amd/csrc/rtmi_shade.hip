@@ -332,7 +332,7 @@ RTMI_TRAVERSAL_KERNEL_W(4) void k_ao_trace(SceneDev scene, const AoFrame *__rest
 		occ[idx] = h.pos != RTMI_MISS ? 1 : 0;
 		return false;
 	};
-	trace_queue<true, false, false>(scene, stack + threadIdx.x, counter, items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
+	trace_queue<true, false, false>(scene, stack + threadIdx.x, counter, items, tune, 0.0, 0.0, 0.0, fetch, emit);
 }
 
 // The colour of an opaque hit (shader.cpp:481-522) and its reflected child (:527-537, :643).
@@ -576,9 +576,11 @@ static int run_chunk(rtmi_shader *sh, const Chunk &c, uint64_t n, const rtmi_tra
 			                   c.wants_ao, c.shadowed, c.ao_at, ao_cnt, c.ao);
 			int *slot = queue_slot(sh->scene, st, who);
 			if (!slot) return -1;
-			Tune tune = refill_threshold();
-			tune.thresh = (int)std::min(64u, env_uint("RTMI_REFILL_AO", 64));
-			hipLaunchKernelGGL(k_ao_trace, dim3(persistent_grid_of(sh->scene, reinterpret_cast<const void *>(k_ao_trace), cap * c.spp)), dim3(kBlock),
+			const uint32_t ao_grid = persistent_grid_of(sh->scene, reinterpret_cast<const void *>(k_ao_trace), cap * c.spp);
+			Tune tune = launch_tune(refill_threshold(), ao_grid, cap * c.spp);
+			static const unsigned refill_ao = std::min(64u, env_uint("RTMI_REFILL_AO", 64));
+			tune.thresh = (int)refill_ao;
+			hipLaunchKernelGGL(k_ao_trace, dim3(ao_grid), dim3(kBlock),
 			                   sh->scene->stack_bytes, st, sh->scene->dev, c.ao, ao_cnt, cap * c.spp, c.spp, p.ao_radius, slot, tune, c.ao_occ);
 		}
 		hipLaunchKernelGGL(k_shade_post, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, S, c.rays[g], c.hits, cnt, last, c.spp,

@@ -64,7 +64,7 @@ RTMI_TRAVERSAL_KERNEL void k_trace_rays(SceneDev S, const rtmi_ray *__restrict__
 		else out[base + idx] = hit_record(S, h);
 		return false;
 	};
-	trace_queue<ANY, false, false>(S, stack + threadIdx.x, counter, items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
+	trace_queue<ANY, false, false>(S, stack + threadIdx.x, counter, items, tune, 0.0, 0.0, 0.0, fetch, emit);
 }
 
 // Shader::findOcclusionNew (shader.cpp:140-232) in ONE launch: the ambient-occlusion ray of item k·spp + s is built in
@@ -96,7 +96,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_AO_WAVES) void k_ao_occlusion(SceneDev S, const dou
 		occluded[idx] = h.pos != RTMI_MISS ? 1 : 0;
 		return false;
 	};
-	trace_queue<true, false, false>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
+	trace_queue<true, false, false>(S, stack + threadIdx.x, counter, n_items, tune, 0.0, 0.0, 0.0, fetch, emit);
 }
 
 // Shader::generateNormalShadows (shader.cpp:105-138) in one launch: the shadow ray of hit k (origin P + 0.01·normal, direction
@@ -126,7 +126,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_AO_WAVES) void k_shadow_occlusion(SceneDev S, const
 		occluded[k] = h.pos != RTMI_MISS ? 1 : 0;
 		return false;
 	};
-	trace_queue<true, false, false>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
+	trace_queue<true, false, false>(S, stack + threadIdx.x, counter, n_items, tune, 0.0, 0.0, 0.0, fetch, emit);
 }
 
 // Shader::generateSoftShadows (shader.cpp:41-103) in one launch, like k_ao_occlusion: the ray of item k·n_points + i·divY + j
@@ -160,7 +160,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_AO_WAVES) void k_soft_shadow(SceneDev S, const doub
 		contrib[idx] = (h.pos != RTMI_MISS && S.tris[h.pos].object != hits[idx / n_points].object) ? 1 : 0;
 		return false;
 	};
-	trace_queue<false, false, false>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, 0.0, 0.0, 0.0, fetch, emit);
+	trace_queue<false, false, false>(S, stack + threadIdx.x, counter, n_items, tune, 0.0, 0.0, 0.0, fetch, emit);
 }
 
 // factor = 1 − contributors / n_points, 1 when there is none (shader.cpp:100-102)
@@ -219,7 +219,7 @@ RTMI_TRAVERSAL_KERNEL void k_primary_closest(SceneDev S, int *__restrict__ count
 		out[(uint64_t)i * cam.x_res + j] = hit_record(S, h);
 		return false;
 	};
-	trace_queue<false, false, true>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, cam.eye[0], cam.eye[1], cam.eye[2],
+	trace_queue<false, false, true>(S, stack + threadIdx.x, counter, n_items, tune, cam.eye[0], cam.eye[1], cam.eye[2],
 	                                fetch, emit);
 }
 
@@ -241,7 +241,7 @@ RTMI_TRAVERSAL_KERNEL void k_primary_work(SceneDev S, int *__restrict__ counter,
 		return true;
 	};
 	auto emit = [&](uint32_t, const HitQ &, RayD &) { return false; };
-	trace_queue<false, true, true>(S, stack + threadIdx.x, counter, n_items, tune.thresh, tune.vote_node, tune.vote_leaf, cam.eye[0], cam.eye[1], cam.eye[2],
+	trace_queue<false, true, true>(S, stack + threadIdx.x, counter, n_items, tune, cam.eye[0], cam.eye[1], cam.eye[2],
 	                               fetch, emit, &w);
 	unsigned long long v[6] = {w.nodes, w.tests, w.node_slots, w.test_slots, w.wait_leaf, w.wait_idle};
 	for (int k = 0; k < 6; ++k) {
@@ -296,8 +296,23 @@ Tune refill_threshold() { // the tuning environment is read once
 		x.thresh = (int)std::min(64u, env_uint("RTMI_REFILL", 16));
 		x.vote_node = (int)env_uint("RTMI_VOTE_NODE", 1);
 		x.vote_leaf = (int)env_uint("RTMI_VOTE_LEAF", 3);
+		x.chunk = kQueueChunk;
+		x.tail_chunk = kTailChunk;
 		return x;
 	}();
+	return t;
+}
+
+// Claim sizes a launch starts with (trace_queue adapts them to what its rays cost): kQueueChunk items per atomic, fewer
+// when the launch is so small that this would hand every resident wave its whole share in one or two claims (a launch
+// cannot end before its slowest wave has; smaller first claims leave something to balance with).  tail_chunk is the floor
+// of the end-game halving.
+Tune launch_tune(Tune t, uint32_t grid, uint64_t n_items) {
+	static const unsigned fixed = env_uint("RTMI_CHUNK", 0);
+	if (fixed) { t.chunk = fixed; t.tail_chunk = std::max(16u, fixed / 2u); return t; }
+	const uint64_t per_wave = n_items / std::max<uint64_t>(1, (uint64_t)grid * (kBlock / 64));
+	t.chunk = per_wave < kQueueChunk ? kQueueChunk / 2u : kQueueChunk;
+	t.tail_chunk = 32u;
 	return t;
 }
 
@@ -329,6 +344,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	s->xyz_hash = hash_doubles(xyz, 9 * n);
 	s->d_queue = nullptr;
 	s->h_error = nullptr;
+	s->dev.n_top = 0;
 	s->dev.guard = env_uint("RTMI_GUARD", kGuard);
 	s->dev.error = nullptr;
 	{
@@ -472,6 +488,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		fail("rtmi_scene_create: upload failed");
 		return nullptr;
 	}
+	s->dev.n_top = wide.n_top;
 	s->dev.nodes = d_nodes; s->dev.wnodes = d_wnodes; s->dev.tris = d_tris; s->dev.root_ref = root_ref; s->dev.absmax = absmax;
 	for (int a = 0; a < 3; ++a) { s->dev.qlo[a] = qlo[a]; s->dev.qstep[a] = qstep[a]; }
 	s->info.n_nodes = nodes.size();
@@ -550,10 +567,11 @@ static int trace_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, rtmi_hit
 	int *slot = queue_slot(s, (hipStream_t)stream, who);
 	if (!slot) return -1;
 	const uint32_t grid = persistent_grid(s, k_trace_rays<ANY>, n);
-	Tune tune = refill_threshold();
+	Tune tune = launch_tune(refill_threshold(), grid, n);
 	// occlusion rays are often short (an AO ray with tmax = 2 rarely gets past the top of the tree): fetching their
 	// successors pays only for larger groups of lanes (C4 room, 33 M AO rays: 2.21 ms at 16, 1.82 ms at 48; heavy occlusion rays prefer 16: 32 is the compromise)
-	if (ANY) tune.thresh = (int)std::min(64u, env_uint("RTMI_REFILL_ANY", 32));
+	static const unsigned refill_any = std::min(64u, env_uint("RTMI_REFILL_ANY", 32));
+	if (ANY) tune.thresh = (int)refill_any;
 	hipLaunchKernelGGL(k_trace_rays<ANY>, dim3(grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, d_rays, n, d_n, mul,
 	                   slot, tune, d_out, d_occ);
 	return launch_check(who);
@@ -583,11 +601,13 @@ static int ao_occlusion_dev(rtmi_scene *s, const double *d_normals, const rtmi_r
 	}
 	int *slot = queue_slot(s, (hipStream_t)stream, who);
 	if (!slot) return -1;
-	Tune tune = refill_threshold();
+	const uint32_t grid = persistent_grid(s, k_ao_occlusion, n * spp);
+	Tune tune = launch_tune(refill_threshold(), grid, n * spp);
 	// building a ray costs more than reading one, and rays of length <= radius are short: refill whole waves
 	// (C4 room, 33 M rays: 2.39 / 1.97 / 1.85 / 1.81 ms at 16 / 32 / 48 / 64)
-	tune.thresh = (int)std::min(64u, env_uint("RTMI_REFILL_AO", 64));
-	hipLaunchKernelGGL(k_ao_occlusion, dim3(persistent_grid(s, k_ao_occlusion, n * spp)), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev,
+	static const unsigned refill_ao = std::min(64u, env_uint("RTMI_REFILL_AO", 64));
+	tune.thresh = (int)refill_ao;
+	hipLaunchKernelGGL(k_ao_occlusion, dim3(grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev,
 	                   s->d_v1_orig, d_normals, d_rays, d_hits, (uint32_t)(n * spp), spp, radius, seed, slot, tune, d_occ);
 	return launch_check(who);
 }
@@ -605,9 +625,11 @@ static int shadow_occlusion_dev(rtmi_scene *s, const double *d_normals, const rt
 	}
 	int *slot = queue_slot(s, (hipStream_t)stream, who);
 	if (!slot) return -1;
-	Tune tune = refill_threshold();
-	tune.thresh = (int)std::min(64u, env_uint("RTMI_REFILL_ANY", 32));
-	hipLaunchKernelGGL(k_shadow_occlusion, dim3(persistent_grid(s, k_shadow_occlusion, n)), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev,
+	const uint32_t grid = persistent_grid(s, k_shadow_occlusion, n);
+	Tune tune = launch_tune(refill_threshold(), grid, n);
+	static const unsigned refill_any = std::min(64u, env_uint("RTMI_REFILL_ANY", 32));
+	tune.thresh = (int)refill_any;
+	hipLaunchKernelGGL(k_shadow_occlusion, dim3(grid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev,
 	                   s->d_v1_orig, d_normals, d_rays, d_hits, (uint32_t)n, light_center[0], light_center[1], light_center[2], slot, tune, d_occ);
 	return launch_check(who);
 }
@@ -628,9 +650,11 @@ static int soft_shadow_dev(rtmi_scene *s, const double *d_normals, const rtmi_ra
 		if (!slot) return -1;
 		uint32_t div_x = n_points, div_y = 1; // shader.cpp:60-63
 		while (div_x % 2 == 0) { div_x /= 2; div_y *= 2; }
-		Tune tune = refill_threshold();
-		tune.thresh = (int)std::min(64u, env_uint("RTMI_REFILL_SOFT", 48)); // C4 room, 52 M rays: 4.76 / 4.20 / 4.00 / 4.04 ms at 16 / 32 / 48 / 64
-		hipLaunchKernelGGL(k_soft_shadow, dim3(persistent_grid(s, k_soft_shadow, n * n_points)), dim3(kBlock), s->stack_bytes, st, s->dev, s->d_v1_orig,
+		const uint32_t grid = persistent_grid(s, k_soft_shadow, n * n_points);
+		Tune tune = launch_tune(refill_threshold(), grid, n * n_points);
+		static const unsigned refill_soft = std::min(64u, env_uint("RTMI_REFILL_SOFT", 48)); // C4 room, 52 M rays: 4.76 / 4.20 / 4.00 / 4.04 ms at 16 / 32 / 48 / 64
+		tune.thresh = (int)refill_soft;
+		hipLaunchKernelGGL(k_soft_shadow, dim3(grid), dim3(kBlock), s->stack_bytes, st, s->dev, s->d_v1_orig,
 		                   d_normals, d_rays, d_hits, (uint32_t)(n * n_points), n_points, div_x, div_y, light_center[0], light_center[1],
 		                   light_center[2], slot, tune, d_contrib);
 	}
@@ -852,8 +876,9 @@ int rtmi_primary_closest_hit_dev(rtmi_scene *s, const rtmi_camera *cam, double s
 	if (n_items > 0xff000000ull) return fail(std::string(who) + ": too many pixels for one launch");
 	int *slot = queue_slot(s, (hipStream_t)stream, who);
 	if (!slot) return -1;
-	hipLaunchKernelGGL(k_primary_closest, dim3(persistent_grid(s, k_primary_closest, n_items)), dim3(kBlock), s->stack_bytes,
-	                   (hipStream_t)stream, s->dev, slot, (uint32_t)n_items, *cam, sx, sy, g, refill_threshold(), d_out);
+	const uint32_t pgrid = persistent_grid(s, k_primary_closest, n_items);
+	hipLaunchKernelGGL(k_primary_closest, dim3(pgrid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, slot, (uint32_t)n_items, *cam, sx,
+	                   sy, g, launch_tune(refill_threshold(), pgrid, n_items), d_out);
 	return launch_check(who);
 }
 
@@ -868,8 +893,9 @@ int rtmi_primary_work_dev(rtmi_scene *s, const rtmi_camera *cam, double sx, doub
 	if (n_items > 0xff000000ull) return fail(std::string(who) + ": too many pixels for one launch");
 	int *slot = queue_slot(s, (hipStream_t)stream, who);
 	if (!slot) return -1;
-	hipLaunchKernelGGL(k_primary_work, dim3(persistent_grid(s, k_primary_work, n_items)), dim3(kBlock), s->stack_bytes, (hipStream_t)stream,
-	                   s->dev, slot, (uint32_t)n_items, *cam, sx, sy, g, refill_threshold(), (unsigned long long *)d_counts);
+	const uint32_t pgrid = persistent_grid(s, k_primary_work, n_items);
+	hipLaunchKernelGGL(k_primary_work, dim3(pgrid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, slot, (uint32_t)n_items, *cam, sx, sy,
+	                   g, launch_tune(refill_threshold(), pgrid, n_items), (unsigned long long *)d_counts);
 	return launch_check(who);
 }
 

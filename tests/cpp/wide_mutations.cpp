@@ -16,7 +16,13 @@ int main() {
 	{ Wide4 m = w; m.nodes[10].w[5] -= 1; if (check_wide(b, m) == 0) { printf("FAIL hi.x byte of child 0 lowered\n"); return 1; } }
 	{ Wide4 m = w; m.nodes[7].w[4] += 0x100; if (check_wide(b, m) == 0) { printf("FAIL lo.x byte of child 1 raised\n"); return 1; } }
 	{ Wide4 m = w; m.nodes[3].w[10] += 1; if (check_wide(b, m) == 0) { printf("FAIL inner base shifted\n"); return 1; } }
-	{ Wide4 m = w; m.nodes[20].w[11] -= 8; if (check_wide(b, m) == 0) { printf("FAIL leaf base shifted\n"); return 1; } }
+	{ // a node that HAS a leaf child (the top levels, laid out first, are all inner nodes)
+		size_t k = 0;
+		while (k < w.nodes.size() && ((w.nodes[k].w[3] >> 28) == ((w.nodes[k].w[3] >> 24) & 15u))) ++k;
+		if (k == w.nodes.size()) { printf("FAIL no node with a leaf child\n"); return 1; }
+		Wide4 m = w; m.nodes[k].w[11] -= 8; if (check_wide(b, m) == 0) { printf("FAIL leaf base shifted\n"); return 1; }
+	}
+	if (w.n_top < 5 || w.n_top > 21) { printf("FAIL n_top %u\n", w.n_top); return 1; }
 	{ Wide4 m = w; m.stack_need -= 1; if (check_wide(b, m) == 0) { printf("FAIL stack bound too small\n"); return 1; } }
 	{ Wide4 m = w; m.nodes[5].w[3] -= 1; if (check_wide(b, m) == 0) { printf("FAIL x exponent lowered\n"); return 1; } }
 	printf("ok\n");
