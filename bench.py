@@ -16,6 +16,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline_traversal  the closest-hit kernel the headline `value` times: SURVEY.md §8d's max(flop / 157.3 TFLOP/s,
                       cache bytes / 34.5 TB/s L2) from the algorithmic work per ray, both terms printed
   roofline_formfactor the form-factor kernel (98 % of "form-factor + solve time"): fp64 vector-ALU bound
+  tile_launch         N=1 only: the frame as the 8 launches one rank of 8 issues, against the one full-frame launch
   solver / formfactor the 64 K-patch solve (synthetic F, row-sharded over the ranks) and the form-factor build
   cpu_baseline        the oracle (CPU restatement, OpenMP) on a bounded sample of the same rays, N=1 only
   cpu_baseline_radiosity  the metric's second half on the CPU: the oracle (OpenMP) on the C2 box, and the COMPILED REFERENCE's
@@ -123,17 +124,18 @@ def main():
     rays_rank = sum(multi.pixels_of_rank(x_res, y_res, TILE[0], TILE[1], (rank + s) % world, world) for s in range(spp))
     rays_total = spp * n_pix
 
-    # At N > 1 a rank traces N launches of 1/N of the tiles per step.  A launch of a million rays leaves every resident wave
-    # with one chunk of the queue and ends in a long tail (tools/quick_tiles.py: 8 such launches on one stream take 2.2x the
-    # time of one full-frame launch, on 4 streams 1.05x), so the independent launches of a step go round-robin over up to
-    # 4 HIP streams (the box's hardware-queue limit) and the tail of one overlaps the start of the next.
-    lanes = [torch.cuda.Stream() for _ in range(min(4, spp))] if spp > 1 else []
-    lane_handles = [st.cuda_stream for st in lanes] or [stream]
+    # At N > 1 a rank traces 1/N of the tiles of each of N samples per step.  As N launches they would each end in their own
+    # tail (tile_launch below measures it at N = 1: 8 launches on one stream take 1.9x the one full-frame launch); the
+    # library takes the samples of a step in ONE launch with one work queue (rtmi_primary_closest_hit_samples_dev).
+    MAXS = rt.api.MAX_SAMPLES_PER_LAUNCH
 
     def step():
-        for s in range(spp):
-            scene.primary_dev(cam, frames[s].data_ptr(), sx=offs[s][0], sy=offs[s][1], tile=TILE,
-                              tile_first=(rank + s) % world, tile_stride=world, stream=lane_handles[s % len(lane_handles)])
+        if spp == 1:
+            scene.primary_dev(cam, frames[0].data_ptr(), sx=offs[0][0], sy=offs[0][1], tile=TILE, stream=stream)
+            return
+        for s0 in range(0, spp, MAXS):
+            scene.primary_samples_dev(cam, [(offs[s][0], offs[s][1], (rank + s) % world, frames[s].data_ptr()) for s in range(s0, min(spp, s0 + MAXS))],
+                                      tile=TILE, tile_stride=world, stream=stream)
 
     for _ in range(args.warmup):
         step()
@@ -146,10 +148,8 @@ def main():
         ev[k][1].record()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
-    if spp == 1:
-        kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps          # average duration of one launch (HIP events)
-    else:
-        kernel_ms = dt * 1e3 / (args.steps * spp)                               # launches overlap across streams: wall time per launch
+    launches_per_step = (spp + MAXS - 1) // MAXS
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * launches_per_step)   # average duration of one launch (HIP events)
     mrays = rays_total * args.steps / dt / 1e6
 
     # traversal work of the frame (diagnostic kernel, untimed) -> roofline of the closest-hit kernel
@@ -159,13 +159,13 @@ def main():
     visits, tests, vslots, tslots, wleaf, widle = (int(v) for v in counts.cpu())
     flop_per_ray = (visits * FLOP_NODE_VISIT + tests * FLOP_TRI_TEST) / n_pix
     l2_bytes_per_ray = (visits * BYTES_NODE + tests * BYTES_TRI) / n_pix + BYTES_HIT
-    rays_per_launch = rays_rank / spp
+    rays_per_launch = rays_rank / launches_per_step
     trav_tflops = flop_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e12
     cache_gbs = l2_bytes_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e9
     valu_frac, cache_frac = trav_tflops / FP32_PEAK_TFLOPS, cache_gbs / L2_PEAK_GBS
     # fraction of roofline = max(flop / vector-ALU peak, cache bytes / L2 bandwidth), algorithmic work per ray
     roofline_traversal = {
-        "kernel": "k_primary_closest", "bound": "l2" if cache_frac >= valu_frac else "valu",
+        "kernel": "k_primary_closest" if spp == 1 else "k_primary_closest_samples", "bound": "l2" if cache_frac >= valu_frac else "valu",
         "achieved": round(cache_gbs if cache_frac >= valu_frac else trav_tflops, 3),
         "peak": L2_PEAK_GBS if cache_frac >= valu_frac else FP32_PEAK_TFLOPS,
         "unit": "GB/s through L1/L2 (algorithmic node + triangle + hit bytes)" if cache_frac >= valu_frac else "TFLOP/s (fp32-equivalent; fp64 flop = 2)",
@@ -179,6 +179,45 @@ def main():
         "node_step_lanes_holding_a_leaf": round(wleaf / max(1, vslots), 3), "node_step_lanes_without_a_ray": round(widle / max(1, vslots), 3),
         "traffic": None,
     }
+
+    # ------------------------------------------------------------------ what a rank's launch shape at N = 8 costs, measured at N = 1
+    # The same frame as 8 launches of every 8th tile (what one rank of 8 issues per step), on one stream and dealt over
+    # 4 streams as step() does, against the one full-frame launch: efficiency = full-frame time / time of the 8 launches.
+    tile_launch = None
+    if world == 1:
+        side = [torch.cuda.Stream() for _ in range(4)]
+
+        def eighths(handles):
+            for s in range(8):
+                scene.primary_dev(cam, frames[0].data_ptr(), tile=TILE, tile_first=s, tile_stride=8, stream=handles[s % len(handles)])
+
+        def wall_ms(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3 / reps
+
+        reps = max(3, min(10, args.steps))
+        full_ms = wall_ms(lambda: scene.primary_dev(cam, frames[0].data_ptr(), tile=TILE, stream=stream), reps)
+        one_ms = wall_ms(lambda: eighths([stream]), reps)
+        four_ms = wall_ms(lambda: eighths([st.cuda_stream for st in side]), reps)
+        # the same rays as ONE launch of 8 samples x every 8th tile: what bench.py --gpus 8 issues per rank and step
+        set_ms = wall_ms(lambda: scene.primary_samples_dev(cam, [(0.5, 0.5, s, frames[0].data_ptr()) for s in range(8)], tile=TILE, tile_stride=8,
+                                                           stream=stream), reps)
+        scene.primary_dev(cam, frames[0].data_ptr(), tile=TILE, stream=stream)      # frames[0] again holds the full frame
+        torch.cuda.synchronize()
+        tile_launch = {"workload": "the C3 frame as 8 launches of every 8th 64x64 tile (one rank's launches at N = 8)",
+                       "full_frame_ms": round(full_ms, 3), "eight_launches_one_stream_ms": round(one_ms, 3),
+                       "eight_launches_four_streams_ms": round(four_ms, 3), "one_launch_of_eight_samples_ms": round(set_ms, 3),
+                       "tile_launch_efficiency_one_stream": round(full_ms / one_ms, 3),
+                       "tile_launch_efficiency_four_streams": round(full_ms / four_ms, 3),
+                       "tile_launch_efficiency": round(full_ms / set_ms, 3),
+                       "note": "bench.py --gpus N issues a rank's N tile sets as one launch (rtmi_primary_closest_hit_samples_dev), so "
+                               "`tile_launch_efficiency` = full frame / one launch of 8 samples is the one that applies; the other two are "
+                               "what a caller pays who launches per tile set (4 streams: depends on how the streams fall on the 4 hardware queues)"}
 
     # ------------------------------------------------------------------ radiosity solve, C5 (synthetic F)
     solver = None
@@ -609,6 +648,7 @@ def main():
                                "max_leaf": int(info.max_leaf_size), "build_seconds": round(info.build_seconds, 2),
                                "device_MB": round(info.device_bytes / 1e6, 1)}},
             "roofline": roofline, "roofline_traversal": roofline_traversal, "roofline_formfactor": roofline_formfactor,
+            "tile_launch": tile_launch,
             "solver": solver, "formfactor": formfactor,
             "cpu_baseline": cpu, "cpu_baseline_radiosity": cpu_rad, "reference_so": have_ref_so, "c1_reference": c1, "frame": frame,
         }

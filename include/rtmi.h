@@ -117,6 +117,22 @@ int rtmi_primary_closest_hit_dev(rtmi_scene *, const rtmi_camera *cam, double sx
                                  uint32_t tile_h, uint32_t tile_first, uint32_t tile_stride, rtmi_hit *d_out,
                                  void *stream);
 int rtmi_primary_rays_dev(const rtmi_camera *cam, double sx, double sy, rtmi_ray *d_rays, void *stream);
+/* Several samples per pixel in ONE launch (no counterpart in the reference, whose loop shoots the one ray through the
+ * pixel centre): sample k shoots ray(i,j) with offsets (sx, sy)[k] through the pixels of tiles tile_first[k],
+ * tile_first[k] + tile_stride, ... and writes its own full-size frame d_out[k] (frames may not overlap unless the
+ * samples' tiles are disjoint).  Same rays and records as n_samples calls of rtmi_primary_closest_hit_dev, but one
+ * work queue: the launches of a rank that holds 1/N of the tiles of N samples do not each end in their own tail.
+ * `samples` is a HOST array (copied into the launch), n_samples <= RTMI_MAX_SAMPLES_PER_LAUNCH. */
+#define RTMI_MAX_SAMPLES_PER_LAUNCH 16u
+typedef struct rtmi_primary_sample {
+	double sx, sy;        /* offsets inside the pixel, 0.5 = centre */
+	uint32_t tile_first;  /* first tile of this sample */
+	uint32_t reserved;    /* 0 */
+	rtmi_hit *d_out;      /* device frame of x_res·y_res records */
+} rtmi_primary_sample;
+int rtmi_primary_closest_hit_samples_dev(rtmi_scene *, const rtmi_camera *cam, uint32_t tile_w, uint32_t tile_h,
+                                         uint32_t tile_stride, const rtmi_primary_sample *samples, uint32_t n_samples,
+                                         void *stream);
 /* Diagnostic (no counterpart in the reference): the traversal work of the same frame of primary rays,
  * ADDED to d_counts[0] (node visits, two child boxes each), d_counts[1] (exact triangle tests) and
  * d_counts[2], d_counts[3] (lane slots the waves spent in the node loop / the triangle loop: 64 per

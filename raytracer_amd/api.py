@@ -41,6 +41,13 @@ class rtmi_camera(C.Structure):
                 ("x_res", C.c_uint32), ("y_res", C.c_uint32)]
 
 
+class rtmi_primary_sample(C.Structure):
+    _fields_ = [("sx", C.c_double), ("sy", C.c_double), ("tile_first", C.c_uint32), ("reserved", C.c_uint32), ("d_out", C.c_void_p)]
+
+
+MAX_SAMPLES_PER_LAUNCH = 16
+
+
 class rtmi_scene_info(C.Structure):
     _fields_ = [("n_tris", C.c_uint64), ("n_nodes", C.c_uint64), ("n_leaves", C.c_uint64), ("max_depth", C.c_uint32),
                 ("max_leaf_size", C.c_uint32), ("build_seconds", C.c_double), ("device_bytes", C.c_uint64),
@@ -74,7 +81,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_
 # every symbol include/rtmi.h declares (tests check the library exports exactly these)
 SYMBOLS = [
     "rtmi_last_error", "rtmi_device_count", "rtmi_triangle_intersection", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_get_info", "rtmi_scene_check",
-    "rtmi_closest_hit", "rtmi_closest_hit_dev", "rtmi_camera_setup", "rtmi_primary_closest_hit_dev",
+    "rtmi_closest_hit", "rtmi_closest_hit_dev", "rtmi_camera_setup", "rtmi_primary_closest_hit_dev", "rtmi_primary_closest_hit_samples_dev",
     "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev", "rtmi_shadow_occlusion_dev", "rtmi_debug_check_hierarchy",
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev", "rtmi_radiosity_solve_noalloc_dev",
@@ -112,6 +119,7 @@ def _load():
     L.rtmi_any_hit_dev.argtypes = [vp, vp, u64, vp, vp]
     L.rtmi_camera_setup.argtypes = [vp, vp, vp, dbl, vp, vp, u32, u32, C.POINTER(rtmi_camera)]
     L.rtmi_primary_closest_hit_dev.argtypes = [vp, C.POINTER(rtmi_camera), dbl, dbl, u32, u32, u32, u32, vp, vp]
+    L.rtmi_primary_closest_hit_samples_dev.argtypes = [vp, C.POINTER(rtmi_camera), u32, u32, u32, C.POINTER(rtmi_primary_sample), u32, vp]
     L.rtmi_primary_rays_dev.argtypes = [C.POINTER(rtmi_camera), dbl, dbl, vp, vp]
     L.rtmi_primary_work_dev.argtypes = [vp, C.POINTER(rtmi_camera), dbl, dbl, vp, vp]
     L.rtmi_shadow_rays_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
@@ -339,6 +347,13 @@ class Scene:
         _check(lib.rtmi_primary_closest_hit_dev(self.handle, C.byref(cam.c), sx, sy, tile[0], tile[1], tile_first,
                                                 tile_stride, d_out, stream))
 
+    def primary_samples_dev(self, cam, samples, tile=(0, 0), tile_stride=1, stream=0):
+        """rtmi_primary_closest_hit_samples_dev: samples = [(sx, sy, tile_first, d_out), ...] (at most MAX_SAMPLES_PER_LAUNCH),
+        one launch and one work queue for all of them; same records as one primary_dev call per sample."""
+        arr = (rtmi_primary_sample * len(samples))()
+        for k, (sx, sy, first, d_out) in enumerate(samples):
+            arr[k].sx, arr[k].sy, arr[k].tile_first, arr[k].reserved, arr[k].d_out = sx, sy, first, 0, d_out
+        _check(lib.rtmi_primary_closest_hit_samples_dev(self.handle, C.byref(cam.c), tile[0], tile[1], tile_stride, arr, len(samples), stream))
 
     # -- wavefront stages (device buffers): secondary rays from hit records --
     def shadow_rays_dev(self, d_normals, d_rays, d_hits, n, light_center, d_out, stream=0):

@@ -179,7 +179,7 @@ __device__ __forceinline__ D3 primary_dir(const rtmi_camera &c, uint32_t i, uint
 }
 
 struct PrimaryGrid {
-	uint32_t tile_w, tile_h, tiles_x, tile_first, tile_stride;
+	uint32_t tile_w, tile_h, tiles_x, tile_first, tile_stride, n_tiles;
 	uint32_t blk_w, blk_h;            // pixels one workgroup owns (multiples of 8)
 	uint32_t blocks_x, blocks_per_tile;
 };
@@ -196,7 +196,7 @@ __device__ __forceinline__ bool primary_pixel(const PrimaryGrid &g, const rtmi_c
 	const uint32_t ly = (b / g.blocks_x) * g.blk_h + (sq / sq_x) * 8 + (in >> 3);
 	j = tx * g.tile_w + lx;
 	i = ty * g.tile_h + ly;
-	return lx < g.tile_w && ly < g.tile_h && j < cam.x_res && i < cam.y_res;
+	return tile < g.n_tiles && lx < g.tile_w && ly < g.tile_h && j < cam.x_res && i < cam.y_res;
 }
 
 // Primary rays generated in registers, 0 input bytes per ray.
@@ -217,6 +217,46 @@ RTMI_TRAVERSAL_KERNEL void k_primary_closest(SceneDev S, int *__restrict__ count
 		uint32_t i, j;
 		primary_pixel(g, cam, idx / per_block, idx % per_block, i, j);
 		out[(uint64_t)i * cam.x_res + j] = hit_record(S, h);
+		return false;
+	};
+	trace_queue<false, false, true>(S, stack + threadIdx.x, counter, n_items, tune, cam.eye[0], cam.eye[1], cam.eye[2],
+	                                fetch, emit);
+}
+
+// Several samples per pixel, one queue: item -> (sample, item of that sample's tiles).  The sample table is a kernel argument
+// (constant memory), read per lane when a ray is fetched and when its record is written.
+struct SampleSet {
+	rtmi_primary_sample s[RTMI_MAX_SAMPLES_PER_LAUNCH];
+	uint32_t n, items_per_sample;
+};
+
+RTMI_TRAVERSAL_KERNEL void k_primary_closest_samples(SceneDev S, int *__restrict__ counter, uint32_t n_items, rtmi_camera cam,
+                                                                    PrimaryGrid g, Tune tune, SampleSet set) {
+	extern __shared__ int stack[];
+	__shared__ rtmi_primary_sample table[RTMI_MAX_SAMPLES_PER_LAUNCH];
+	for (uint32_t k = 0; k < RTMI_MAX_SAMPLES_PER_LAUNCH; ++k) // uniform index into the argument, one lane stores
+		if (threadIdx.x == k && k < set.n) table[k] = set.s[k];
+	__syncthreads();
+	const uint32_t per_block = g.blk_w * g.blk_h;
+	auto pixel = [&](uint32_t idx, uint32_t &smp, uint32_t &i, uint32_t &j) {
+		smp = idx / set.items_per_sample;
+		const uint32_t k = idx - smp * set.items_per_sample;
+		PrimaryGrid gs = g;
+		gs.tile_first = table[smp].tile_first;
+		return primary_pixel(gs, cam, k / per_block, k % per_block, i, j);
+	};
+	auto fetch = [&](uint32_t idx, RayD &R) {
+		uint32_t smp, i, j;
+		if (!pixel(idx, smp, i, j)) return false;
+		const D3 d = primary_dir(cam, i, j, table[smp].sx, table[smp].sy);
+		R.dx = d.x; R.dy = d.y; R.dz = d.z;
+		R.tmax = RTMI_INFINITY;
+		return true;
+	};
+	auto emit = [&](uint32_t idx, const HitQ &h, RayD &) {
+		uint32_t smp, i, j;
+		pixel(idx, smp, i, j);
+		table[smp].d_out[(uint64_t)i * cam.x_res + j] = hit_record(S, h);
 		return false;
 	};
 	trace_queue<false, false, true>(S, stack + threadIdx.x, counter, n_items, tune, cam.eye[0], cam.eye[1], cam.eye[2],
@@ -854,6 +894,7 @@ static int64_t primary_grid(const rtmi_camera *cam, uint32_t tile_w, uint32_t ti
 	if (tile_first >= n_tiles) return 0;
 	const uint64_t local = (n_tiles - tile_first + tile_stride - 1) / tile_stride;
 	g.tile_w = tile_w; g.tile_h = tile_h; g.tiles_x = tiles_x; g.tile_first = tile_first; g.tile_stride = tile_stride;
+	g.n_tiles = (uint32_t)n_tiles;
 	g.blk_w = std::min(64u, (tile_w + 7) / 8 * 8);
 	g.blk_h = std::min(std::max(8u, env_uint("RTMI_BLK_H", 32) / 8 * 8), (tile_h + 7) / 8 * 8);
 	g.blocks_x = (tile_w + g.blk_w - 1) / g.blk_w;
@@ -879,6 +920,39 @@ int rtmi_primary_closest_hit_dev(rtmi_scene *s, const rtmi_camera *cam, double s
 	const uint32_t pgrid = persistent_grid(s, k_primary_closest, n_items);
 	hipLaunchKernelGGL(k_primary_closest, dim3(pgrid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, slot, (uint32_t)n_items, *cam, sx,
 	                   sy, g, launch_tune(refill_threshold(), pgrid, n_items), d_out);
+	return launch_check(who);
+}
+
+int rtmi_primary_closest_hit_samples_dev(rtmi_scene *s, const rtmi_camera *cam, uint32_t tile_w, uint32_t tile_h,
+                                         uint32_t tile_stride, const rtmi_primary_sample *samples, uint32_t n_samples,
+                                         void *stream) {
+	const char *who = "rtmi_primary_closest_hit_samples_dev";
+	if (check_scene(s, who)) return -1;
+	if (!cam || (!samples && n_samples)) return fail(std::string(who) + ": NULL argument");
+	if (n_samples > RTMI_MAX_SAMPLES_PER_LAUNCH)
+		return fail(std::string(who) + ": at most " + std::to_string(RTMI_MAX_SAMPLES_PER_LAUNCH) + " samples per launch");
+	if (n_samples == 0) return 0;
+	// every sample gets the item range of the one with the most tiles; a sample's items beyond its last tile hold no ray
+	SampleSet set;
+	memset(&set, 0, sizeof set);
+	uint32_t lowest = samples[0].tile_first;
+	for (uint32_t k = 0; k < n_samples; ++k) {
+		if (!samples[k].d_out) return fail(std::string(who) + ": sample without a frame");
+		set.s[k] = samples[k];
+		lowest = std::min(lowest, samples[k].tile_first);
+	}
+	PrimaryGrid g;
+	const int64_t grid = primary_grid(cam, tile_w, tile_h, lowest, tile_stride, g, who);
+	if (grid <= 0) return (int)grid;
+	const uint64_t per_sample = (uint64_t)grid * g.blk_w * g.blk_h, n_items = per_sample * n_samples;
+	if (n_items > 0xff000000ull) return fail(std::string(who) + ": too many pixels for one launch");
+	set.n = n_samples;
+	set.items_per_sample = (uint32_t)per_sample;
+	int *slot = queue_slot(s, (hipStream_t)stream, who);
+	if (!slot) return -1;
+	const uint32_t pgrid = persistent_grid(s, k_primary_closest_samples, n_items);
+	hipLaunchKernelGGL(k_primary_closest_samples, dim3(pgrid), dim3(kBlock), s->stack_bytes, (hipStream_t)stream, s->dev, slot,
+	                   (uint32_t)n_items, *cam, g, launch_tune(refill_threshold(), pgrid, n_items), set);
 	return launch_check(who);
 }
 

@@ -112,6 +112,44 @@ def test_g2_tiles_shard_without_overlap(rt):
     assert union.tobytes() == full.tobytes()
 
 
+def test_samples_in_one_launch_equal_one_launch_per_sample(rt):
+    """rtmi_primary_closest_hit_samples_dev: 5 samples with their own pixel offsets and first tiles (ragged tiles, one sample
+    starting beyond the last tile, two samples sharing one frame on disjoint tiles) write, byte for byte, what one
+    rtmi_primary_closest_hit_dev call per sample writes; untouched pixels stay untouched."""
+    import torch
+    g = load_golden("g2_test1.npz")
+    scene = rt.Scene(g["tris"], g["tri_obj"])
+    cam = rt.Camera.from_cam14(g["cam"], g["res"])
+    n = cam.x_res * cam.y_res
+    st = torch.cuda.current_stream().cuda_stream
+    tile, stride = (48, 40), 4
+    n_tiles = -(-cam.x_res // tile[0]) * -(-cam.y_res // tile[1])
+    spec = [(0.5, 0.5, 0, 0), (0.25, 0.75, 3, 1), (0.9, 0.1, 2, 2), (0.5, 0.5, 1, 0), (0.3, 0.3, n_tiles + 1, 3)]   # (sx, sy, first, frame)
+    one = [torch.full((n * 24,), 0xAB, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    per = [torch.full((n * 24,), 0xAB, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    for sx, sy, first, f in spec:
+        scene.primary_dev(cam, per[f].data_ptr(), sx=sx, sy=sy, tile=tile, tile_first=first, tile_stride=stride, stream=st)
+    scene.primary_samples_dev(cam, [(sx, sy, first, one[f].data_ptr()) for sx, sy, first, f in spec], tile=tile, tile_stride=stride, stream=st)
+    torch.cuda.synchronize()
+    scene.check()
+    for a, b in zip(one, per):
+        assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes()
+    assert (per[0].cpu().numpy() != 0xAB).any() and (per[3].cpu().numpy() == 0xAB).all()
+    # whole frames: 3 samples x all tiles (tile_stride 1, tile (0, 0) = the frame as one tile)
+    outs = [torch.zeros(n * 24, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    offs = [(0.5, 0.5), (0.1, 0.2), (0.8, 0.6)]
+    scene.primary_samples_dev(cam, [(sx, sy, 0, o.data_ptr()) for (sx, sy), o in zip(offs, outs)], stream=st)
+    for (sx, sy), o in zip(offs, outs):
+        ref = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+        scene.primary_dev(cam, ref.data_ptr(), sx=sx, sy=sy, stream=st)
+        torch.cuda.synchronize()
+        assert o.cpu().numpy().tobytes() == ref.cpu().numpy().tobytes()
+    with pytest.raises(rt.RtmiError):
+        scene.primary_samples_dev(cam, [(0.5, 0.5, 0, outs[0].data_ptr())] * 17, stream=st)
+    with pytest.raises(rt.RtmiError):
+        scene.primary_samples_dev(cam, [(0.5, 0.5, 0, None)], stream=st)
+
+
 def test_g3_shadow_and_ao_any_hit(rt):
     g = load_golden("g2_test1.npz")
     scene = rt.Scene(g["tris"], g["tri_obj"])
