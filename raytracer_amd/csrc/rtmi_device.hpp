@@ -235,7 +235,11 @@ __device__ __forceinline__ int sbyte(uint32_t w, int k) { return (int)(w << (24 
 // the child's number in the two lowest bits; 0xffffffff = not hit.  Five min/max pairs sort the four words.
 __device__ __forceinline__ int node_step(const SceneDev &S, const RayW &r, float tbest, int cur, int &sp, int *stack, const WNode *top = nullptr,
                                          uint32_t n_top = 0) {
+#ifdef RTMI_NODE_STRIDE // experiment: nodes at a stride of 64 B (none straddles a cache line), 48 B of each used
+	const WNode *np = reinterpret_cast<const WNode *>(reinterpret_cast<const char *>(S.wnodes) + (size_t)(uint32_t)cur * RTMI_NODE_STRIDE);
+#else
 	const WNode *np = S.wnodes + cur;
+#endif
 	uint4 a, b, c;
 #if RTMI_TOP_LDS
 	if ((uint32_t)cur < n_top) { a = top[cur].a; b = top[cur].b; c = top[cur].c; } // the levels every ray starts in: from LDS
@@ -420,9 +424,13 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 	// Once fewer items are left than one full chunk per resident wave, claims are therefore smaller (the wave judges that from
 	// the counter value its previous claim returned); all other claims stay large to keep the atomics on the counter rare.
 	// The claim size adapts to what the rays cost (wave-uniform): claims are atomics on ONE counter, which serialise at about
-	// 8 ns each, so a wave should not claim more often than every few dozen iterations — cheap rays (a room's primary rays,
-	// short any-hit rays) keep large claims; rays that take hundreds of steps (the 1 Mi-triangle soup) come down to 64-item
-	// claims, one 8 x 8 pixel square, which balances the waves better (C3: 2.84 ms with 256-item claims, 2.59 ms adaptive).
+	// 8 ns each, so a wave should not claim more often than every few dozen rounds — cheap rays (a room's primary rays,
+	// short any-hit rays) keep large claims; a wave that went more than 128 rounds on one claim halves its next one (down to
+	// 64 items, one 8 x 8 pixel square), one that came back within 40 doubles it again.  Measured (MI355X, round 2): C3
+	// 2.84 ms with fixed 256-item claims, 2.57 ms with fixed 64 — but fixed 64 makes the room's primary rays 0.52 ms instead
+	// of 0.31 (32 K atomics); this rule: C3 2.72-2.75 ms, room 0.30 ms.  Guided self-scheduling (claim <= 1/2 or 1/4 of an
+	// even share of what is left, floor 32) was measured too: C3 2.65-2.69 ms, but every cheap launch 8-30 % slower (its end
+	// game is all small claims); not kept.
 	uint32_t cur_chunk = tune.chunk, since_claim = 0;
 	const uint32_t resident_waves = gridDim.x * (kBlock / 64u);
 	uint32_t seen = 0; // the counter as of this wave's last claim

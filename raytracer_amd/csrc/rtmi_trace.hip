@@ -330,6 +330,11 @@ unsigned env_uint(const char *name, unsigned dflt) {
 	return v > 0 ? (unsigned)v : dflt;
 }
 
+#ifdef RTMI_NODE_STRIDE
+static const size_t kNodeStride = RTMI_NODE_STRIDE;
+#else
+static const size_t kNodeStride = sizeof(WNode);
+#endif
 Tune refill_threshold() { // the tuning environment is read once
 	static const Tune t = [] {
 		Tune x;
@@ -504,7 +509,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	QNode *d_nodes = nullptr;
 	WNode *d_wnodes = nullptr;
 	GTri *d_tris = nullptr;
-	const size_t nb = std::max<size_t>(1, nodes.size()) * sizeof(QNode), wb = std::max<size_t>(1, wnodes.size()) * sizeof(WNode), tb = tris.size() * sizeof(GTri);
+	const size_t nb = std::max<size_t>(1, nodes.size()) * sizeof(QNode), wb = std::max<size_t>(1, wnodes.size()) * kNodeStride, tb = tris.size() * sizeof(GTri);
 	if (hipMalloc(&d_nodes, nb) != hipSuccess || hipMalloc(&d_wnodes, wb) != hipSuccess || hipMalloc(&d_tris, tb) != hipSuccess ||
 	    hipMalloc(&s->d_v1_orig, v1.size() * sizeof(double)) != hipSuccess) {
 		if (d_nodes) (void)hipFree(d_nodes);
@@ -519,7 +524,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	}
 	bool ok = true;
 	if (!nodes.empty()) ok = ok && hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(QNode), hipMemcpyHostToDevice) == hipSuccess;
-	if (!wnodes.empty()) ok = ok && hipMemcpy(d_wnodes, wnodes.data(), wnodes.size() * sizeof(WNode), hipMemcpyHostToDevice) == hipSuccess;
+	if (!wnodes.empty()) ok = ok && hipMemcpy2D(d_wnodes, kNodeStride, wnodes.data(), sizeof(WNode), sizeof(WNode), wnodes.size(), hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(d_tris, tris.data(), tb, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(s->d_v1_orig, v1.data(), v1.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
 	if (!ok) {
