@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--ff-rows", type=int, default=-1, help="-1: build the whole 64K-patch form-factor matrix and solve on it; K>0: a sample of K rows; 0: skip")
     ap.add_argument("--no-solver", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-tiles", action="store_true", help="skip the tile_launch section (profiling runs: its launches would mix into the per-kernel averages)")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -184,7 +185,7 @@ def main():
     # The same frame as 8 launches of every 8th tile (what one rank of 8 issues per step), on one stream and dealt over
     # 4 streams as step() does, against the one full-frame launch: efficiency = full-frame time / time of the 8 launches.
     tile_launch = None
-    if world == 1:
+    if world == 1 and not args.no_tiles:
         side = [torch.cuda.Stream() for _ in range(4)]
 
         def eighths(handles):

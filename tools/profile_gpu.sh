@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu --ff-rows 4096"
+BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu --no-tiles --ff-rows 4096"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
 echo "trace pass done"
 i=0

@@ -103,7 +103,7 @@ if "k_form_factors" in traffic:
         ff["hbm_bytes_per_launch"] = t["fetch_raw"] + t["write"]
         ff["hbm_bytes_per_entry_fetch"] = round(t["fetch_raw"] / entries, 2)
         ff["hbm_bytes_per_entry_write"] = round(t["write"] / entries, 2)
-        ff["note"] = "FETCH_SIZE uncorrected (scattered 16-byte loads: the x2 of a streaming read does not apply); WRITE_SIZE counts the one-dword-per-lane stores of a row at about twice their bytes (profiles/README.md, calibration)"
+        ff["note"] = "FETCH_SIZE uncorrected (scattered 16-byte loads: the x2 of a streaming read does not apply); WRITE_SIZE is exact for these store patterns (profiles/README.md, calibration): the bytes above 4 per entry are partial 64-byte sectors of scattered patch ids"
     if "l2_hit_rate" in t:
         ff["l2_hit_rate"] = round(t["l2_hit_rate"], 4)
     ms = [float(r["AverageNs"]) for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))) if "k_form_factors" in r["Name"] and "flat" not in r["Name"]]
@@ -116,7 +116,16 @@ if "k_form_factors" in traffic:
     g = geo.get("k_form_factors")
     if g:
         ff["scratch_bytes"] = int(g.get("Scratch_Size") or 0)
-        ff["vgprs"] = int(g.get("VGPR_Count") or 0) + int(g.get("Accum_VGPR_Count") or 0)
+        ff["vgprs_in_rocprof_trace"] = int(g.get("VGPR_Count") or 0) + int(g.get("Accum_VGPR_Count") or 0)   # the trace's unit is not registers per lane
+    try:   # registers per lane from the code object's own note (tools/kernel_resources.sh compiles the device side, ~20 s)
+        import re, subprocess
+        notes = subprocess.run(["bash", os.path.join(root, "tools", "kernel_resources.sh"), os.path.join(root, "raytracer_amd", "csrc", "rtmi_formfactor.hip")],
+                               check=True, capture_output=True, text=True).stdout
+        m = re.search(r"_ZN4rtmi14k_form_factorsE\S*\s+\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", notes)
+        if m:
+            ff["scratch_bytes"], ff["vgprs"] = int(m.group(1)), int(m.group(2))
+    except Exception:
+        pass
     out["k_form_factors"] = ff
 json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 print("\n".join(lines))
