@@ -199,8 +199,9 @@ int rtmi_soft_shadow_dev(rtmi_scene *, const double *d_normals, const rtmi_ray *
                          const double light_center[3], uint32_t n_points, uint8_t *d_contrib, double *d_factor, void *stream);
 
 /* ---- frame: Scene::Trace + Shader::Shade as a wavefront -------------------------------------------------
- * Replaces the recursion Scene::Trace (Render2/scene.cpp:127-155) -> Shader::Shade (Render2/shader.cpp:395-645, the
- * branch the shipped main.cpp runs: scene.radiosity == NULL) -> Scene::Trace ..., and the pixel loop + ToneMap of
+ * Replaces the recursion Scene::Trace (Render2/scene.cpp:127-155) -> Shader::Shade (Render2/shader.cpp:395-645: the
+ * branch the shipped main.cpp runs, scene.radiosity == NULL, and with RTMI_SHADE_RADIOSITY_BRANCH the other one,
+ * :431-478) -> Scene::Trace ..., and the pixel loop + ToneMap of
  * Rasterizer::Serial_Normal_Raster (Render2/rasterizer.cpp:79-88, 219-233).  One generation of the ray tree is one
  * batch: closest hit, shadow ray of generateNormalShadows (:105-138), ambient-occlusion rays of findOcclusionNew
  * (:140-232), Phong / microfacet colour (:485-519), reflected (:527-537) and refracted (:542-641) children; the
@@ -227,7 +228,15 @@ typedef struct rtmi_trace_params {
 	uint32_t ao_rays;        /* shader.cpp:481: 10; 0 = occlusion 1 (shader.cpp:142) */
 	double ao_radius;        /* shader.cpp:481: 2.0 */
 	uint64_t seed;           /* AO square points: stream (seed, ray-tree path, ray index, sample); the reference's are unseeded */
+	uint32_t flags;          /* 0, or RTMI_SHADE_RADIOSITY_BRANCH */
+	uint32_t reserved;       /* 0 */
 } rtmi_trace_params;
+/* RTMI_SHADE_RADIOSITY_BRANCH: Shade as it runs when scene.radiosity != NULL (Render2/shader.cpp:431-478), as shipped: the
+ * radiosity lookup (trace_ray, :433) and the 100-ray occlusion (:434) are computed by the reference and used by nothing —
+ * the lines that would use them are commented out (:457-465) — so the colour of a hit is the specular sum over the lights
+ * (:467-472), returned (:477) before shadows, reflection and refraction; misses and the depth limit as in the other
+ * branch.  The dead work is not done. */
+#define RTMI_SHADE_RADIOSITY_BRANCH 1u
 typedef struct rtmi_shader rtmi_shader;
 rtmi_shader *rtmi_shader_create(rtmi_scene *, const double *tri_normals, const rtmi_material *object_materials,
                                 uint32_t n_objects, const rtmi_light *lights, uint32_t n_lights);

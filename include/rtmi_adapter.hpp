@@ -172,6 +172,8 @@ public:
 		}
 		params_.max_tree_depth = scene.max_tree_depth;
 		params_.ao_rays = ao_rays; params_.ao_radius = ao_radius; params_.seed = seed;
+		params_.flags = scene.radiosity != nullptr ? RTMI_SHADE_RADIOSITY_BRANCH : 0u; // which branch Shade takes, shader.cpp:431
+		params_.reserved = 0;
 		rtmi_shader_destroy(shader_);
 		shader_ = rtmi_shader_create(geometry.handle(), nrm.data(), mats.data(), (uint32_t)mats.size(), lights.data(), (uint32_t)lights.size());
 		return shader_ != nullptr;
@@ -224,7 +226,7 @@ private:
 	};
 	template <class ColorT> static void rgb(double *p, const ColorT &c) { p[0] = c.red; p[1] = c.green; p[2] = c.blue; }
 	rtmi_shader *shader_ = nullptr;
-	rtmi_trace_params params_ = {1, 10, 2.0, 1};
+	rtmi_trace_params params_ = {1, 10, 2.0, 1, 0, 0};
 };
 
 // ------------------------------------------------------------------------------------------------ radiosity

@@ -212,16 +212,16 @@ class Oracle:
         return B, s
 
     def trace(self, tris, normals, tri_object, mats18, lights6, o, d, max_depth=1, ao_rays=10, ao_radius=2.0, seed=1,
-              generation=1, first_index=0, bvh=None):
-        """rto_trace: Scene::Trace + Shader::Shade on n rays -> n × 3 colours"""
+              generation=1, first_index=0, bvh=None, radiosity_branch=False):
+        """rto_trace_flags: Scene::Trace + Shader::Shade on n rays -> n × 3 colours (radiosity_branch: shader.cpp:431-478)"""
         tris = _f64(tris, (-1, 9)); normals = _f64(normals, (-1, 3)); mats18 = _f64(mats18, (-1, 18))
         lights6 = _f64(lights6, (-1, 6)); o = _f64(o, (-1, 3)); d = _f64(d, (-1, 3))
         tob = np.ascontiguousarray(tri_object, np.uint32)
         rgb = np.zeros((len(o), 3))
-        self.lib.rto_trace(C.c_long(len(tris)), _p(tris), _p(normals), _p(tob), _p(mats18), _p(lights6),
-                           C.c_int(len(lights6)), bvh, C.c_uint32(max_depth), C.c_uint32(ao_rays), C.c_double(ao_radius),
-                           C.c_uint64(seed), C.c_long(len(o)), _p(o), _p(d), C.c_uint32(generation),
-                           C.c_uint64(first_index), _p(rgb))
+        self.lib.rto_trace_flags(C.c_long(len(tris)), _p(tris), _p(normals), _p(tob), _p(mats18), _p(lights6),
+                                 C.c_int(len(lights6)), bvh, C.c_uint32(max_depth), C.c_uint32(ao_rays), C.c_double(ao_radius),
+                                 C.c_uint64(seed), C.c_uint32(1 if radiosity_branch else 0), C.c_long(len(o)), _p(o), _p(d),
+                                 C.c_uint32(generation), C.c_uint64(first_index), _p(rgb))
         return rgb
 
     def tone_map(self, rgb):
@@ -422,6 +422,11 @@ class Reference:
 
     def rad_setup(self, h):
         return self.lib.ref_rad_setup(h)
+
+    def rad_attach(self, h, mode):
+        """scene.radiosity for Shader::Shade's radiosity branch: 0 = NULL, 1 = the Radiosity of rad_setup, 2 = a bare one."""
+        if self.lib.ref_rad_attach(h, C.c_int(mode)) != 0:
+            raise RuntimeError("ref_rad_attach: no Radiosity to attach (rad_setup first)")
 
     def rad_elements(self, h, n_el):
         verts = np.zeros((n_el, 9)); nrm = np.zeros((n_el, 3)); obj = np.zeros(n_el, np.int32)

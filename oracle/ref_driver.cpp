@@ -537,6 +537,30 @@ void ref_rad_scatter_B(void *h, double *out) {
 	for (size_t i = 0; i < s->elems.size(); ++i) out[i] = s->elems[i]->radiosityValue;
 }
 
+// Makes Shader::Shade take its radiosity branch (shader.cpp:431-478): scene.radiosity != NULL.
+//   mode 0: detach;  1: the Radiosity of ref_rad_setup, tempQuadVector = its element list (what main.cpp's radiosity run has);
+//   2: a bare Radiosity (helper + empty element list) for scenes without a BSP: trace_ray then answers Green, and the
+//      branch's colour does not depend on it (the uses of radiosityAmbient and occlusion are commented out, :457-465).
+int ref_rad_attach(void *h, int mode) {
+	RefScene *s = (RefScene *)h;
+	if (mode == 0) { s->scene.radiosity = NULL; return 0; }
+	if (mode == 1) {
+		if (!s->rad) return -1;
+		*s->rad->tempQuadVector = s->elems;
+		s->scene.radiosity = s->rad;
+		return 0;
+	}
+	Radiosity *R = new Radiosity();
+	R->scene = &s->scene;
+	R->cam = &s->cam;
+	R->numOfElements = 0;
+	R->quadTreeRoot = NULL;
+	R->radiosityHelper = new Radiosity_Helper(&s->scene);
+	R->tempQuadVector = new vector<QuadTreeNode *>(0);
+	s->scene.radiosity = R;
+	return 0;
+}
+
 // ---- radiosity display path (Rasterizer::Radiosity_Raster, rasterizer.cpp:408-470)
 // QuadTreeNode::radiosityValue of every element (what setRadiosityForAllElements would write)
 void ref_rad_set_element_radiosity(void *h, const double *B) {

@@ -766,6 +766,7 @@ typedef struct {
 	uint32_t max_depth, ao_rays;
 	double ao_radius;
 	uint64_t seed;
+	uint32_t flags; /* RTO_SHADE_RADIOSITY: Shade's radiosity branch (scene.radiosity != NULL) */
 } shade_ctx;
 
 static const v3 kBackground = {0.15, 0.25, 0.35}; /* scene.cpp:21 */
@@ -817,6 +818,18 @@ static v3 shade(const shade_ctx *c, v3 O, v3 D, int32_t tri, double distance, ui
 	v3 R;
 	v3 color = {0, 0, 0};                                /* :427-429 */
 
+	if (c->flags & RTO_SHADE_RADIOSITY) {
+		/* shader.cpp:431-478 as shipped: radiosityAmbient (trace_ray, :433) and occlusion (findOcclusionNew with 100 rays, :434)
+		 * are computed and never used — the lines that would use them are commented out (:457-465) — so the colour is the
+		 * specular sum over the lights (:467-472), returned before shadows, reflection and refraction (:477). */
+		for (int i = 0; i < c->n_lights; ++i) {
+			const v3 LightPos = ld3(c->lights + 6 * i), emission = ld3(c->lights + 6 * i + 3);
+			const v3 L = unit(sub(LightPos, P));             /* :453 */
+			const v3 RR = add(scl(-1.0, L), scl(2.0 * dot(L, N), N)); /* :467 */
+			color = add(color, cmul(emission, scl(pow(max2(0.0, dot(E, RR)), e), specular))); /* :472 */
+		}
+		return color;
+	}
 	const double occ = occlusion(c, P, Ns, k0, path);    /* :481 */
 	for (int i = 0; i < c->n_lights; ++i) {              /* :485-519 */
 		const v3 LightPos = ld3(c->lights + 6 * i), emission = ld3(c->lights + 6 * i + 3);
@@ -894,8 +907,16 @@ void rto_trace(long n_tris, const double *tris, const double *normals, const uin
                const double *lights6, int n_lights, const rto_bvh *bvh, uint32_t max_tree_depth, uint32_t ao_rays,
                double ao_radius, uint64_t seed, long n_rays, const double *o, const double *d, uint32_t generation,
                uint64_t first_index, double *rgb) {
+	rto_trace_flags(n_tris, tris, normals, tri_object, mats18, lights6, n_lights, bvh, max_tree_depth, ao_rays, ao_radius, seed, 0u,
+	                n_rays, o, d, generation, first_index, rgb);
+}
+
+void rto_trace_flags(long n_tris, const double *tris, const double *normals, const uint32_t *tri_object, const double *mats18,
+                     const double *lights6, int n_lights, const rto_bvh *bvh, uint32_t max_tree_depth, uint32_t ao_rays,
+                     double ao_radius, uint64_t seed, uint32_t flags, long n_rays, const double *o, const double *d,
+                     uint32_t generation, uint64_t first_index, double *rgb) {
 	shade_ctx c = {n_tris, tris, normals, mats18, lights6, tri_object, n_lights, bvh, max_tree_depth, ao_rays,
-	               ao_radius, seed};
+	               ao_radius, seed, flags};
 #pragma omp parallel for schedule(dynamic, 64)
 	for (long k = 0; k < n_rays; ++k)
 		st3(rgb + 3 * k, trace_rec(&c, ld3(o + 3 * k), ld3(d + 3 * k), generation, first_index + (uint64_t)k, 1));

@@ -152,6 +152,13 @@ void rto_trace(long n_tris, const double *tris, const double *normals, const uin
                const double *lights6, int n_lights, const rto_bvh *bvh, uint32_t max_tree_depth, uint32_t ao_rays,
                double ao_radius, uint64_t seed, long n_rays, const double *o, const double *d, uint32_t generation,
                uint64_t first_index, double *rgb);
+/* the same with flags: RTO_SHADE_RADIOSITY = Shader::Shade's radiosity branch (shader.cpp:431-478, scene.radiosity != NULL)
+ * as shipped: the colour is the specular sum over the lights, nothing else */
+#define RTO_SHADE_RADIOSITY 1u
+void rto_trace_flags(long n_tris, const double *tris, const double *normals, const uint32_t *tri_object, const double *mats18,
+                     const double *lights6, int n_lights, const rto_bvh *bvh, uint32_t max_tree_depth, uint32_t ao_rays,
+                     double ao_radius, uint64_t seed, uint32_t flags, long n_rays, const double *o, const double *d,
+                     uint32_t generation, uint64_t first_index, double *rgb);
 /* rasterizer.cpp:79-88 */
 void rto_tone_map(long n, const double *rgb, uint8_t *out);
 

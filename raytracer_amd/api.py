@@ -69,7 +69,11 @@ RASTER_NORMAL, RASTER_ANTI_ALIASING, RASTER_DEPTH_OF_FIELD = 0, 1, 2
 
 
 class rtmi_trace_params(C.Structure):
-    _fields_ = [("max_tree_depth", C.c_uint32), ("ao_rays", C.c_uint32), ("ao_radius", C.c_double), ("seed", C.c_uint64)]
+    _fields_ = [("max_tree_depth", C.c_uint32), ("ao_rays", C.c_uint32), ("ao_radius", C.c_double), ("seed", C.c_uint64),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+SHADE_RADIOSITY_BRANCH = 1   # include/rtmi.h: RTMI_SHADE_RADIOSITY_BRANCH
 
 
 # include/rtmi.h: rtmi_material (18 doubles), rtmi_light (6 doubles)
@@ -409,7 +413,8 @@ class Shader:
     normals: n_tris x 3 (triNormal); materials: n_objects x 18 (diffuse, specular, ambient, reflectivity, translucency,
     Phong_exp, ref_index, roughness); lights: n_lights x 6 (Center(GetBox(light)), emission)."""
 
-    def __init__(self, scene, normals, materials, lights, max_tree_depth=1, ao_rays=10, ao_radius=2.0, seed=1):
+    def __init__(self, scene, normals, materials, lights, max_tree_depth=1, ao_rays=10, ao_radius=2.0, seed=1, radiosity_branch=False):
+        """radiosity_branch: Shade as it runs with scene.radiosity != NULL (shader.cpp:431-478)."""
         self.scene = scene
         nrm = _np(normals, np.float64, (-1, 3))
         mats = _np(materials, np.float64, (-1, MATERIAL_DOUBLES))
@@ -421,7 +426,8 @@ class Shader:
         if not h:
             raise RtmiError(lib.rtmi_last_error().decode())
         self.handle = C.c_void_p(h)
-        self.params = rtmi_trace_params(int(max_tree_depth), int(ao_rays), float(ao_radius), int(seed))
+        self.params = rtmi_trace_params(int(max_tree_depth), int(ao_rays), float(ao_radius), int(seed),
+                                        SHADE_RADIOSITY_BRANCH if radiosity_branch else 0, 0)
 
     def close(self):
         if getattr(self, "handle", None):

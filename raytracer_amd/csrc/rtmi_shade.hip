@@ -171,7 +171,7 @@ __global__ void k_batch_roots(uint64_t first, uint64_t n, uint64_t *__restrict__
 // shadow ray (:116-127).  `last`: the children would be generation max_tree_depth+1, for which Trace returns the
 // termination colour without casting (scene.cpp:134-137), so they are folded in at once.
 __global__ void __launch_bounds__(kReserveBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) k_shade_pre(ShadeDev S, const rtmi_ray *__restrict__ rays, const rtmi_hit *__restrict__ hits,
-                            const uint32_t *__restrict__ d_count, int first, int last, Node *__restrict__ nodes,
+                            const uint32_t *__restrict__ d_count, int first, int last, int radiosity_branch, Node *__restrict__ nodes,
                             rtmi_ray *__restrict__ shadow, uint8_t *__restrict__ wants_ao, uint32_t *__restrict__ kid_count,
                             rtmi_ray *__restrict__ kid_rays, Node *__restrict__ kid_nodes) {
 	const uint64_t count = *d_count;
@@ -197,7 +197,22 @@ __global__ void __launch_bounds__(kReserveBlock) __attribute__((amdgpu_waves_per
 					const rtmi_material &m = S.mats[h.object];
 					const D3 Ns = ld(S.normals + 3 * (size_t)h.tri); // hit.normal = triNormal, object.cpp:17
 					const D3 P = hit_point(r, S.v1_orig + 3 * (size_t)h.tri, Ns);
-					if (refracts(m)) {
+					if (radiosity_branch) {
+						// shader.cpp:431-478 as shipped: radiosityAmbient (:433) and occlusion (:434) are used by nothing (:457-465
+						// are comments), so the hit's colour is the specular sum over the lights, returned at :477
+						const D3 N = unit(Ns);          // :416
+						const D3 E = unit(ld(r.o) - P); // :417
+						const D3 specular = ld(m.specular);
+						D3 color = d3(0, 0, 0);         // :427-429
+						for (uint32_t i = 0; i < S.n_lights; ++i) {
+							const D3 emission = ld(S.lights[i].emission);
+							const D3 L = unit(ld(S.lights[i].center) - P);      // :453
+							const D3 RR = (-1.0 * L) + ((2.0 * dot(L, N)) * N); // :467
+							color = color + cmul(emission, pow_ref(max2(0.0, dot(E, RR)), m.phong_exp) * specular); // :472
+						}
+						ndkind = kFinal;
+						ndc = color;
+					} else if (refracts(m)) {
 						const double kk = m.ref_index;
 						const D3 E = unit(ld(r.o) - P); // :417
 						D3 transl = ld(m.translucency);
@@ -568,8 +583,10 @@ static int run_chunk(rtmi_shader *sh, const Chunk &c, uint64_t n, const rtmi_tra
 		rtmi_ray *kid_rays = last ? nullptr : c.rays[g + 1];
 		Node *kid_nodes = last ? nullptr : c.nodes[g + 1];
 		if (closest_hit_counted(sh->scene, c.rays[g], cap, cnt, 1, c.hits, st, who)) return -1;
+		const int rad = (p.flags & RTMI_SHADE_RADIOSITY_BRANCH) ? 1 : 0;
 		hipLaunchKernelGGL(k_shade_pre, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, S, c.rays[g], c.hits, cnt, g == 0 ? 1 : 0, last,
-		                   c.nodes[g], c.shadow, c.wants_ao, kid_cnt, kid_rays, kid_nodes);
+		                   rad, c.nodes[g], c.shadow, c.wants_ao, kid_cnt, kid_rays, kid_nodes);
+		if (rad) break; // every node is final: no shadow, occlusion, children (the callers planned one level)
 		if (any_hit_counted(sh->scene, c.shadow, cap, cnt, 1, c.shadowed, st, who)) return -1;
 		if (c.spp) {
 			hipLaunchKernelGGL(k_ao_list, grid_for(sh, cap, kReserveBlock), dim3(kReserveBlock), 0, st, S, c.hits, c.nodes[g], c.root, p.seed, cnt,
@@ -599,6 +616,7 @@ static int check_params(const rtmi_trace_params *p, const char *who) {
 	if (!p) return fail(std::string(who) + ": params is NULL");
 	if (p->ao_rays && !(p->ao_radius > 0.0)) return fail(std::string(who) + ": ao_radius must be positive");
 	if (p->max_tree_depth > 16) return fail(std::string(who) + ": max_tree_depth > 16");
+	if (p->flags & ~RTMI_SHADE_RADIOSITY_BRANCH) return fail(std::string(who) + ": unknown flags");
 	return 0;
 }
 
@@ -660,7 +678,8 @@ int rtmi_trace_dev(rtmi_shader *sh, const rtmi_ray *d_rays, uint64_t n, uint32_t
 		return launch_check(who);
 	}
 	Chunk c;
-	if (plan_chunk(sh, n, params->max_tree_depth - generation + 1, params->ao_rays, c, who)) return -1;
+	const bool rad = (params->flags & RTMI_SHADE_RADIOSITY_BRANCH) != 0; // that branch never recurses and shoots no secondary ray
+	if (plan_chunk(sh, n, rad ? 1u : params->max_tree_depth - generation + 1, rad ? 0u : params->ao_rays, c, who)) return -1;
 	for (uint64_t at = 0; at < n; at += c.cap) {
 		const uint64_t m = std::min<uint64_t>(c.cap, n - at);
 		if (hipMemcpyAsync(c.rays[0], d_rays + at, m * sizeof(rtmi_ray), hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -698,7 +717,8 @@ int rtmi_render_frame_sampled_dev(rtmi_shader *sh, const rtmi_camera *cam, const
 	if (params->max_tree_depth == 0) return fail(std::string(who) + ": max_tree_depth must be >= 1 (primary rays are generation 1)");
 	const FrameGrid g = {tile_w, tile_h, tiles_x, tile_first, tile_stride};
 	Chunk c;
-	if (plan_chunk(sh, n, params->max_tree_depth, params->ao_rays, c, who, S)) return -1;
+	const bool rad = (params->flags & RTMI_SHADE_RADIOSITY_BRANCH) != 0;
+	if (plan_chunk(sh, n, rad ? 1u : params->max_tree_depth, rad ? 0u : params->ao_rays, c, who, S)) return -1;
 	for (uint64_t at = 0; at < n; at += c.cap) {
 		const uint64_t m = std::min<uint64_t>(c.cap, n - at);
 		hipLaunchKernelGGL(k_frame_rays, grid_for(sh, m), dim3(256), 0, st, *cam, *raster, S, g, at, m, c.rays[0], c.root);

@@ -176,6 +176,16 @@ def test_adapter_rasterize_beside_the_references_trace(ref, oracle, tmp_path):
     edge = np.abs(256 * s["rgb_d3"] - np.round(256 * s["rgb_d3"])) < 1e-8
     assert not ((px2.reshape(-1, 3) != wp) & ~edge).any()
 
+    # (3) the same Scene with a Radiosity attached: Shade takes its radiosity branch (shader.cpp:431-478), the binding sees
+    #     scene.radiosity != NULL and asks for the same branch; colours beside the reference's own Trace on that object
+    ref.rad_attach(h2, 2)
+    b3 = C.c_void_p(ref.lib.ref_adapter_bind(h2))
+    px3, probe3 = adapter_rasterize(ref, h2, b3, s["res"], 10, 1, o[:6000], d[:6000])
+    want3, _ = ref.trace(h2, o[:6000], d[:6000])
+    ref.rad_attach(h2, 0)
+    assert np.abs(probe3 - want3).max() < 1e-11
+    assert not np.array_equal(px3, px2)
+
 
 def test_adapter_radiosity_raster_beside_the_references_trace_ray(ref, oracle, tmp_path):
     """rtmi_host::RadiosityBinding::Radiosity_Raster on the reference's own QuadTreeNode list, Camera and PPM_Image beside

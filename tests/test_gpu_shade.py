@@ -129,6 +129,44 @@ def test_test1_frame_as_shipped(rt, oracle):
     assert dpx.max() <= int(256 * 0.85 * 0.1) + 1
 
 
+def test_radiosity_branch_of_shade(rt, oracle):
+    """RTMI_SHADE_RADIOSITY_BRANCH = Shade with scene.radiosity != NULL (shader.cpp:431-478) against the compiled reference's
+    own colours (tests/golden/g9_shade_radiosity.npz): whole studio frames at depth 1 and 3 (the branch never recurses),
+    ToneMap bytes, a ray batch through rtmi_trace_dev, tiles of two ranks, and test1 with the reference's Radiosity."""
+    g = load_golden("g9_shade_radiosity.npz")
+    scene = rt.Scene(g["studio_tris"], g["studio_tri_obj"])
+    cam = rt.Camera.from_cam14(g["studio_cam14"], g["studio_res"])
+    frames = []
+    for depth in (1, 3):
+        sh = rt.Shader(scene, g["studio_normals"], g["studio_mats"], g["studio_lights"], max_tree_depth=depth, ao_rays=10, radiosity_branch=True)
+        rgb, pix = sh.Rasterize(cam)
+        ref = g["studio_rgb_d%d" % depth]
+        assert np.abs(rgb.reshape(-1, 3) - ref).max() < TOL
+        edge = np.abs(256 * ref - np.round(256 * ref)) < 256 * TOL
+        assert not ((pix.reshape(-1, 3) != oracle.tone_map(ref)) & ~edge).any()
+        frames.append(rgb)
+    assert np.array_equal(frames[0], frames[1])
+    a, _ = sh.Rasterize(cam, tile=(32, 24), tile_first=0, tile_stride=2)
+    b, _ = sh.Rasterize(cam, tile=(32, 24), tile_first=1, tile_stride=2)
+    assert np.array_equal(np.where(a != 0, a, b), frames[1]) and not ((a != 0) & (b != 0)).any()
+    o, d, _ = frame_rays(oracle, g["studio_cam14"], g["studio_res"])
+    assert np.array_equal(sh.Trace(rt.make_rays(o[:3000], d[:3000])), frames[1].reshape(-1, 3)[:3000])
+    assert np.array_equal(sh.Trace(rt.make_rays(o[:100], d[:100]), generation=4), np.zeros((100, 3)))   # scene.cpp:134-137 comes first
+    # the other branch on the same shader inputs gives another picture
+    other, _ = rt.Shader(scene, g["studio_normals"], g["studio_mats"], g["studio_lights"], max_tree_depth=1, ao_rays=10).Rasterize(cam)
+    assert not np.array_equal(other, frames[0])
+    # test1 with the reference's own Radiosity object attached
+    s1 = rt.Scene(g["test1_tris"], g["test1_tri_obj"])
+    sh1 = rt.Shader(s1, g["test1_normals"], g["test1_mats"], g["test1_lights"], max_tree_depth=1, ao_rays=10, radiosity_branch=True)
+    d1 = oracle.primary_dirs(oracle.raster_details(g["test1_cam14"], int(g["test1_res"][0]), int(g["test1_res"][1])), g["test1_pix"])
+    o1 = np.tile(g["test1_cam14"][:3], (len(d1), 1))
+    assert np.abs(sh1.Trace(rt.make_rays(o1, d1)) - g["test1_rgb"]).max() < TOL
+    # unknown flags are refused
+    sh1.params.flags = 6
+    with pytest.raises(rt.RtmiError):
+        sh1.Trace(rt.make_rays(o1[:4], d1[:4]))
+
+
 @pytest.mark.parametrize("name,mode", [("aa", 1), ("dof", 2)])
 def test_sampled_raster_loops(rt, oracle, name, mode):
     """Anti_Aliasing / Depth_Of_Field_Effect on the device: colours against the oracle's restated loops (same sample

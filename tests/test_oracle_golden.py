@@ -288,6 +288,29 @@ def test_g8_radiosity_display_path(oracle, stem):
     assert green.any() and (~green & (rgb[:, 0] > 0)).sum() > 1000
 
 
+def test_g9_radiosity_branch_of_shade_bit_exact(oracle):
+    """Shader::Shade with scene.radiosity != NULL (shader.cpp:431-478) as the compiled reference ran it
+    (oracle/gen_golden_radshade.py): the restatement's colours equal the reference's bit for bit — on the studio scene (all six
+    materials; the branch returns before reflection and refraction, so depth 3 = depth 1) and on test1 with the reference's own
+    Radiosity attached."""
+    from conftest import frame_rays
+    g = load_golden("g9_shade_radiosity.npz")
+    o, d, _ = frame_rays(oracle, g["studio_cam14"], g["studio_res"])
+    for depth in (1, 3):
+        got = oracle.trace(g["studio_tris"], g["studio_normals"], g["studio_tri_obj"], g["studio_mats"], g["studio_lights"], o, d,
+                           max_depth=depth, ao_rays=10, radiosity_branch=True)
+        assert np.array_equal(got, g["studio_rgb_d%d" % depth])
+    assert np.array_equal(g["studio_rgb_d1"], g["studio_rgb_d3"])
+    d1 = oracle.primary_dirs(oracle.raster_details(g["test1_cam14"], int(g["test1_res"][0]), int(g["test1_res"][1])), g["test1_pix"])
+    o1 = np.tile(g["test1_cam14"][:3], (len(d1), 1))
+    got = oracle.trace(g["test1_tris"], g["test1_normals"], g["test1_tri_obj"], g["test1_mats"], g["test1_lights"], o1, d1, max_depth=1,
+                       ao_rays=10, radiosity_branch=True)
+    assert np.array_equal(got, g["test1_rgb"])
+    # and it is a different picture from the other branch's
+    other = oracle.trace(g["test1_tris"], g["test1_normals"], g["test1_tri_obj"], g["test1_mats"], g["test1_lights"], o1, d1, max_depth=1, ao_rays=0)
+    assert not np.array_equal(other, got)
+
+
 def test_form_factor_rows_through_the_oracles_hierarchy_equal_the_scan(oracle):
     """rto_form_factors_bvh (used to check rows of the 64 K-patch matrix on the GPU box) against rto_form_factors, the scan
     over all triangles that the golden vectors pin: same doubles, on a box with an occluder and on a random soup."""
