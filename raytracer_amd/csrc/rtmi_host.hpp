@@ -21,6 +21,8 @@ struct rtmi_scene {
 	std::mutex queue_mutex;
 	std::unordered_map<void *, uint32_t> stream_slot;
 	std::unordered_map<const void *, int> blocks_per_cu; // hipOccupancyMaxActiveBlocksPerMultiprocessor per (kernel) at stack_bytes of LDS
+	void *h_small = nullptr, *d_small = nullptr; // host-mapped staging of the host-pointer entries' small batches (lazily made)
+	std::mutex small_mutex;
 	int *h_error;                     // host-mapped word a kernel sets when a wave gives up (SceneDev::error points at it)
 	int n_cus;
 	uint32_t n_objects; // 1 + the largest tri_object seen at creation (materials are looked up by it)
