@@ -271,7 +271,8 @@ def main():
                 if tj.get("k_primary_closest", {}).get("rays_per_launch") == int(rays_per_launch):
                     roofline_traversal["traffic"] = tj["k_primary_closest"]["hbm_bytes"]
                     # PMC shares of the same kernel (rocprofv3 passes of tools/profile_gpu.sh; profiles/<source>_rocprof.md)
-                    for key in ("l2_hit_rate", "valu_active_share_of_wave_cycles", "wait_any_share_of_wave_cycles", "lanes_active_per_valu_instruction"):
+                    for key in ("l2_hit_rate", "valu_active_share_of_wave_cycles", "wait_any_share_of_wave_cycles", "lanes_active_per_valu_instruction",
+                                "valu_issue_utilisation", "valu_instructions_per_ray"):
                         if key in tj["k_primary_closest"]:
                             roofline_traversal[key] = tj["k_primary_closest"][key]
                     roofline_traversal["pmc_source"] = "stored: profiles/%s_rocprof.md" % tj["k_primary_closest"].get("source", "?")

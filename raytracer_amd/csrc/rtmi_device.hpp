@@ -260,9 +260,9 @@ __device__ __forceinline__ int node_step(const SceneDev &S, const RayW &r, float
 	{                                                                                                                         \
 		const float tn = fmaxf(fmaxf(fmaf(ubyte<K>(nxw), ax, bnx), fmaf(ubyte<K>(nyw), ay, bny)), fmaxf(fmaf(ubyte<K>(nzw), az, bnz), 0.0f)); \
 		const float tf = fminf(fminf(fmaf(ubyte<K>(fxw), ax, bfx), fmaf(ubyte<K>(fyw), ay, bfy)), fminf(fmaf(ubyte<K>(fzw), az, bfz), tbest)); \
-		key[K] = (tn <= tf && n_child > K) ? ((__float_as_uint(tn) & ~3u) | K) : 0xffffffffu;                                  \
+		key[K] = (tn <= tf && (K < 2 || n_child > K)) ? ((__float_as_uint(tn) & ~3u) | K) : 0xffffffffu;                       \
 	}
-	RTMI_CHILD(0) RTMI_CHILD(1) RTMI_CHILD(2) RTMI_CHILD(3)
+	RTMI_CHILD(0) RTMI_CHILD(1) RTMI_CHILD(2) RTMI_CHILD(3) // a node has at least two children (check_wide): no count test for 0 and 1
 #undef RTMI_CHILD
 #define RTMI_CE(I, J)                                                                                                         \
 	{                                                                                                                         \

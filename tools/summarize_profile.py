@@ -92,6 +92,12 @@ if "k_primary_closest" in traffic and "hbm_bytes" in traffic["k_primary_closest"
     for key in ("l2_hit_rate", "valu_active_share_of_wave_cycles", "wait_any_share_of_wave_cycles", "lanes_active_per_valu_instruction"):
         if key in t:
             out["k_primary_closest"][key] = round(t[key], 4)
+    a = {c: sum(v) / len(v) for c, v in pmc["k_primary_closest"].items()}
+    if "SQ_INSTS_VALU" in a and "GRBM_GUI_ACTIVE" in a:
+        # a wave64 vector instruction occupies its SIMD's issue for 4 cycles (tools/ub/valu_rate.hip: 3.1 fma_f32 ... 4.7);
+        # 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' cycles of the launch
+        out["k_primary_closest"]["valu_issue_utilisation"] = round(a["SQ_INSTS_VALU"] * 4.0 / (1024.0 * a["GRBM_GUI_ACTIVE"] / 8.0), 3)
+        out["k_primary_closest"]["valu_instructions_per_ray"] = round(a["SQ_INSTS_VALU"] / (3840 * 2160), 1)
 if "k_form_factors" in traffic:
     t = traffic["k_form_factors"]
     a = {c: max(v) for c, v in pmc["k_form_factors"].items()}
