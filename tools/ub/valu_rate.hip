@@ -24,7 +24,9 @@ template <int KIND> __global__ void __launch_bounds__(256) k_rate(float *out, fl
 		if (KIND == 8) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[K]) : "v"(u[(K + 1) & 7]));                         \
 		if (KIND == 9) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[K]));                                                      \
 		if (KIND == 10) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[K]) : "v"((double)m));                                \
-		if (KIND == 11) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[K]) : "v"((double)c));
+		if (KIND == 11) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[K]) : "v"((double)c));                                \
+		if (KIND == 12) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[K]) : "v"(u[K]), "v"(m)); \
+		if (KIND == 13) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[K]) : "v"(u[(K + 1) & 7]));
 		REP8(OP)
 #undef OP
 	}
@@ -52,5 +54,6 @@ int main() {
 	run<0>("v_fma_f32", out); run<1>("v_pk_fma_f32", out); run<2>("v_fma_f64", out); run<3>("v_cvt_f32_ubyte1", out);
 	run<4>("v_max3_f32", out); run<5>("v_min_u32", out); run<6>("v_cndmask_b32", out); run<7>("v_ldexp_f32", out);
 	run<8>("v_mul_lo_u32", out); run<9>("v_rcp_f64", out); run<10>("v_mul_f64", out); run<11>("v_add_f64", out);
+	run<12>("v_fma_mix_f32", out); run<13>("v_add_u32", out);
 	return hipDeviceSynchronize() == hipSuccess ? 0 : 2;
 }
