@@ -237,6 +237,33 @@ def test_generated_100k_face_mesh_loads_and_renders(rt, oracle, tmp_path):
     assert (tri >= 0).mean() > 0.5
 
 
+@pytest.mark.parametrize("stem,n_tris", [("real_full_room", 14676), ("real_buddha", 3367)])
+def test_the_references_large_assets_render(rt, oracle, stem, n_tris):
+    """the reference's own meshes full_room.obj and Golden_Buddha_low.obj (tests/golden/scenes, data
+    fixtures) through the lenient reader, BuildBSP and the frame path at 640x480: primary hits of a pixel sample equal brute
+    force over all triangles, colours of the same sample equal the oracle's Trace (seeded AO stream) within TOL."""
+    import os
+    from conftest import GOLDEN
+    s = rt.BuildScene(os.path.join(GOLDEN, "scenes"), stem, lenient=True)
+    assert len(s["tris"]) == n_tris
+    scene = rt.Scene(s["tris"], s["tri_obj"])
+    sh = rt.Shader(scene, s["normals"], s["mats"], s["lights"], max_tree_depth=2, ao_rays=10, seed=4)
+    cam = rt.Camera.from_cam14(s["cam14"], s["res"])
+    rgb, pix = sh.Rasterize(cam)
+    scene.check()
+    o, d, _ = frame_rays(oracle, s["cam14"], s["res"])
+    sel = np.arange(0, len(d), 61)
+    tri, t, _, _ = oracle.closest_hit(s["tris"], o[sel], d[sel])
+    hits = scene.Cast(rt.make_rays(o[sel], d[sel]))
+    assert np.array_equal(hits["tri"], np.where(tri < 0, rt.MISS, tri).astype(np.uint32)) and np.array_equal(hits["t"], t)
+    assert (tri >= 0).mean() > 0.2                                                         # the mesh is in the picture
+    # the AO stream is keyed by the ray's index in the frame: trace the sample with the same indices
+    want = np.stack([oracle.trace(s["tris"], s["normals"], s["tri_obj"], s["mats"], s["lights"], o[k:k + 1], d[k:k + 1], max_depth=2,
+                                  ao_rays=10, seed=4, first_index=int(k))[0] for k in sel[::8]])
+    assert np.abs(rgb.reshape(-1, 3)[sel[::8]] - want).max() < TOL
+    assert len(np.unique(pix.reshape(-1, 3), axis=0)) > 200                                # a picture, not a constant
+
+
 def test_shader_errors(rt):
     g = load_golden("g6_shade_studio.npz")
     scene = rt.Scene(g["tris"], g["tri_obj"])

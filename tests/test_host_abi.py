@@ -221,6 +221,40 @@ def test_lenient_reader_takes_what_the_references_reader_cannot(tmp_path):
         rt.BuildScene(str(tmp_path), "gone", lenient=True)
 
 
+def test_the_references_large_assets_load():
+    """SURVEY.md §8f rank 3 names two of the reference's own meshes as the point of the row: scenes/full_room.obj (22 `o`
+    groups, 14 676 faces — the reference's reader drops it, every `o` name differs from the object's) and
+    scenes/Golden_Buddha_low.obj (v/vt/vn corners, `g`, `mtllib`, `usemtl`, `s` lines).  Both are data fixtures under
+    tests/golden/scenes with a view of ours (real_*.sdf).  Triangles are checked against an independent parse of the files."""
+    import raytracer_amd as rt
+    scenes = os.path.join(GOLDEN, "scenes")
+
+    def parse(path):          # v lines, f lines; quads as (0,1,2), (0,2,3) like params.cpp:214-241
+        v, tris = [], []
+        for line in open(path):
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                v.append([float(x) for x in t[1:4]])
+            elif t[0] == "f":
+                idx = [int(c.split("/")[0]) - 1 for c in t[1:]]
+                for k in range(1, len(idx) - 1):
+                    tris.append(v[idx[0]] + v[idx[k]] + v[idx[k + 1]])
+        return np.array(tris)
+
+    room = rt.BuildScene(scenes, "real_full_room", lenient=True)
+    want = parse(os.path.join(scenes, "full_room.obj"))
+    assert len(room["tris"]) == 14676 and np.array_equal(room["tris"], want)
+    assert len(rt.BuildScene(scenes, "real_full_room")["tris"]) == 0                       # as the reference: nothing matches
+    n2 = (room["normals"] ** 2).sum(1)                                                    # unit normals; the zero vector for the
+    assert np.all((np.abs(n2 - 1.0) < 1e-9) | (n2 == 0)) and int((n2 == 0).sum()) == 78    # asset's 78 faces without a direction
+    for lenient in (False, True):                                                         # the Buddha's `o` line matches: both modes
+        b = rt.BuildScene(scenes, "real_buddha", lenient=lenient)
+        assert len(b["tris"]) == 3367 and np.array_equal(b["tris"], parse(os.path.join(scenes, "Golden_Buddha_low.obj")))
+    assert rt.check_hierarchy(room["tris"])[0] == 0                                       # its hierarchy keeps every invariant
+
+
 @pytest.mark.parametrize("case", ["n1", "n2", "n3", "n5", "n64", "soup20k", "offset", "flat", "mixed_scales", "grid", "duplicates"])
 def test_hierarchy_invariants_on_the_host(case):
     """rtmi_debug_check_hierarchy (host only): the binary + 4-wide hierarchies rtmi_scene_create builds keep every
