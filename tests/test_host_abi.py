@@ -229,7 +229,7 @@ def test_the_references_large_assets_load():
     import raytracer_amd as rt
     scenes = os.path.join(GOLDEN, "scenes")
 
-    def parse(path):          # v lines, f lines; quads as (0,1,2), (0,2,3) like params.cpp:214-241
+    def parse(path):          # v lines, f lines; a quad is (v1, v2, v3) + (v3, v4, v1), params.cpp:214-241
         v, tris = [], []
         for line in open(path):
             t = line.split()
@@ -239,8 +239,9 @@ def test_the_references_large_assets_load():
                 v.append([float(x) for x in t[1:4]])
             elif t[0] == "f":
                 idx = [int(c.split("/")[0]) - 1 for c in t[1:]]
-                for k in range(1, len(idx) - 1):
-                    tris.append(v[idx[0]] + v[idx[k]] + v[idx[k + 1]])
+                tris.append(v[idx[0]] + v[idx[1]] + v[idx[2]])
+                for k in range(2, len(idx) - 1):
+                    tris.append(v[idx[k]] + v[idx[k + 1]] + v[idx[0]])
         return np.array(tris)
 
     room = rt.BuildScene(scenes, "real_full_room", lenient=True)
