@@ -221,6 +221,26 @@ def test_lenient_reader_takes_what_the_references_reader_cannot(tmp_path):
         rt.BuildScene(str(tmp_path), "gone", lenient=True)
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/rtmi.h is the boundary a C, C++, cgo or ctypes host binds: it must compile as C99 and as C++17 with nothing
+    else included, and a C program using its structs must link against librtmi.so."""
+    src = tmp_path / "use.c"
+    src.write_text('#include "rtmi.h"\n'
+                   'int main(void) {\n'
+                   '  rtmi_primary_sample s = {0.5, 0.5, 0, 0, 0};\n'
+                   '  rtmi_trace_params p = {1, 10, 2.0, 1, RTMI_SHADE_RADIOSITY_BRANCH, 0};\n'
+                   '  unsigned char id[RTMI_COMM_ID_BYTES];\n'
+                   '  (void)s; (void)p; (void)id;\n'
+                   '  return rtmi_scene_check(0) == -1 && rtmi_last_error()[0] ? 0 : 1;\n'
+                   '}\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "use.o")], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-x", "c++", "-I", inc, "-c", str(src), "-o", str(tmp_path / "use_cpp.o")], check=True)
+    lib = os.path.join(ROOT, "raytracer_amd")
+    subprocess.run(["gcc", str(tmp_path / "use.o"), "-L", lib, "-lrtmi", "-Wl,-rpath," + lib, "-o", str(tmp_path / "use")], check=True)
+    assert subprocess.run([str(tmp_path / "use")]).returncode == 0       # no GPU needed: a NULL scene is refused with a message
+
+
 def test_the_references_large_assets_load():
     """SURVEY.md §8f rank 3 names two of the reference's own meshes as the point of the row: scenes/full_room.obj (22 `o`
     groups, 14 676 faces — the reference's reader drops it, every `o` name differs from the object's) and
