@@ -655,6 +655,7 @@ def main():
             "cpu_baseline": cpu, "cpu_baseline_radiosity": cpu_rad, "reference_so": have_ref_so, "c1_reference": c1, "frame": frame,
         }
         print(json.dumps(line), flush=True)
+    multi.close_library_comms()
     if world > 1:
         dist.destroy_process_group()
 

@@ -20,6 +20,7 @@ the owner of device memory and streams.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -563,9 +564,18 @@ class Radiosity:
         st = torch.cuda.current_stream().cuda_stream
         stats = rtmi_solve_stats()
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if (sharded and dist.get_backend() == "nccl") or os.environ.get("RTMI_SOLVE_IN_LIBRARY") == "1":
+        in_library = (sharded and dist.get_backend() == "nccl") or os.environ.get("RTMI_SOLVE_IN_LIBRARY") == "1"
+        if in_library:
             # production: the loop and its RCCL exchange run inside the library (a communicator of one rank works too)
             from . import multi
+            try:
+                multi.library_comm()
+            except RtmiError as e:       # no RCCL to dlopen on this host (every rank sees the same): the torch.distributed loop does the same iteration
+                if not sharded:
+                    raise
+                print("raytracer_amd: the library's RCCL exchange is unavailable (%s): solving through torch.distributed" % e, file=sys.stderr, flush=True)
+                in_library = False
+        if in_library:
             self.B, stats = multi.solve_sharded_library(self.FF.data_ptr(), self.ld, self.n, self.row0, self.n_rows, rho, dE, tol_rel,
                                                         max_sweeps, check_every, stream=st)
         elif sharded:

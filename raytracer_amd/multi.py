@@ -32,17 +32,27 @@ def library_comm(group=None):
     if key in _COMMS:
         return _COMMS[key]
     ident = (C.c_uint8 * 128)()
-    if rank == 0:
-        api._check(api.lib.rtmi_comm_unique_id(ident))
+    box = [None]
+    if rank == 0:      # a failure here (no RCCL to load) must reach the other ranks too, or they would wait for the id for ever
+        box = [bytes(ident)] if api.lib.rtmi_comm_unique_id(ident) == 0 else [api.lib.rtmi_last_error().decode()]
     if world > 1:
-        box = [bytes(ident) if rank == 0 else None]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+    if not isinstance(box[0], bytes):
+        raise api.RtmiError(box[0] or "rtmi_comm_unique_id failed")
+    ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
     h = api.lib.rtmi_comm_create(ident, rank, world)
     if not h:
         raise api.RtmiError(api.lib.rtmi_last_error().decode())
     _COMMS[key] = (C.c_void_p(h), rank, world)
     return _COMMS[key]
+
+
+def close_library_comms():
+    """Destroys the communicators library_comm() made (call before torch.distributed is shut down)."""
+    from . import api
+    for comm, _, _ in _COMMS.values():
+        api.lib.rtmi_comm_destroy(comm)
+    _COMMS.clear()
 
 
 def solve_sharded_library(d_F, ld, n, row0, n_rows, rho, E, tol_rel=1e-7, max_sweeps=1000, check_every=4, group=None, stream=None):
