@@ -281,6 +281,33 @@ def test_form_factor_path_walk_equals_root_traversal_and_oracle(rt, oracle, monk
         assert np.array_equal(part, F_path[61:136])
 
 
+@pytest.mark.parametrize("stem,row0", [("real_full_room", 7000), ("real_buddha", 1500)])
+def test_form_factors_on_the_references_meshes(rt, oracle, monkeypatch, stem, row0):
+    """The path walk on real meshes (the reference's full_room.obj: furniture inside a room, 78 zero-area faces, vertex
+    normals that are not the geometric ones — so no plane flags; Golden_Buddha_low.obj: a closed curved surface, seen from the inside): 384 rows
+    equal the root-traversal kernel's bit for bit, two of them the oracle's (through its own hierarchy)."""
+    import os
+    from conftest import GOLDEN
+    s = rt.BuildScene(os.path.join(GOLDEN, "scenes"), stem, lenient=True)
+    verts, normals = s["tris"], s["normals"]
+    if stem == "real_buddha":
+        normals = -normals            # the statue from the inside: a closed cavity whose folds hide its patches from each other
+    n = len(verts)
+    scene = rt.Scene(verts)
+    rad = rt.Radiosity(scene, normals, None)
+    monkeypatch.delenv("RTMI_FF_KERNEL", raising=False)
+    F_path = rad.findFormFactor(samples=10, seed=5, row0=row0, n_rows=384).cpu().numpy()[:, :n]
+    scene.check()
+    monkeypatch.setenv("RTMI_FF_KERNEL", "flat")
+    F_flat = rad.findFormFactor(samples=10, seed=5, row0=row0, n_rows=384).cpu().numpy()[:, :n]
+    monkeypatch.delenv("RTMI_FF_KERNEL", raising=False)
+    assert np.array_equal(F_path.view(np.uint32), F_flat.view(np.uint32))
+    assert (F_path > 0).mean() > 0.01 and (F_path == 0).mean() > 0.3
+    for r in (row0 + 3, row0 + 380):
+        want = oracle.form_factors_bvh(verts, normals, 10, 5, row0=r, n_rows=1)[0].astype(np.float32)
+        assert np.array_equal(F_path[r - row0], want)
+
+
 def test_patches_must_be_the_scenes_triangles(rt):
     from raytracer_amd import workloads
     v = workloads.soup(50, seed=2, edge=0.3)
