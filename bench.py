@@ -341,7 +341,7 @@ def main():
                                                   Fb[first:].data_ptr(), ldb, stream)
                 if rc != 0:
                     raise SystemExit(rt.lib.rtmi_last_error().decode())
-            build(0, min(8, nr_s))                                                   # warm-up (builds the path tables too)
+            build(0, min(1024, nr_s))                                                # warm-up: builds the path tables and lets the library time its two kernels
             barrier()
             fe0, fe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n_launch = 0
@@ -384,6 +384,8 @@ def main():
                 except Exception:
                     pass
             formfactor = {"patches": ne, "rows_built_per_rank": nr_s, "seconds": round(ff_s, 4),
+                          "kernel_chosen_by_the_library": {0: "not measured", 1: "k_form_factors (path walk)", 2: "k_form_factors_flat (root traversal)"}.get(
+                              int(rt.lib.rtmi_debug_form_factor_kernel(rad.handle)), "?"),
                           "pair_samples_M_per_s": round(vis_rays / ff_s / 1e6, 1), "samples_per_pair": 10,
                           "note": "a visibility ray is shot only for samples whose two cosines are positive (others add 0 whatever the ray says)",
                           "full_matrix": full, "F_GiB_per_rank": round(nr_s * ldb * 4 / 2**30, 2)}
@@ -454,7 +456,7 @@ def main():
         # GPU: whole matrix + solve
         sc2 = rt.Scene(v2)
         rad2 = rt.Radiosity(sc2, n2, l2)
-        rad2.findFormFactor(samples=10, light_samples=30, seed=1, row0=0, n_rows=8)
+        rad2.findFormFactor(samples=10, light_samples=30, seed=1, row0=0, n_rows=1024)     # warm-up; the library times its two kernels on it
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         F2 = rad2.findFormFactor(samples=10, light_samples=30, seed=1)

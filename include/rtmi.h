@@ -318,7 +318,13 @@ int rtmi_visible_points(rtmi_patches *, uint64_t m, const int32_t *ej, const dou
  * the counter-based generator documented in DESIGN.md (stream = seed, i, j, sample).
  * n = n_patches + 1 (the light is patch n-1, its row is zero) if light_center != NULL, else n_patches.
  * Writes rows [row0, row0+n_rows) of the n × n matrix as fp32: d_F[(r-row0)·ld + c].  Rows shard
- * across GPUs with no communication. */
+ * across GPUs with no communication.
+ * Two kernels compute the same matrix bit for bit: one follows the two patches' paths through the hierarchy
+ * (fast in rooms), one descends from the root (fast in clutter).  The first call on a patch set that covers at least 256 patch
+ * rows of at least 1024 patches times both on its first rows (up to 1024) and keeps the faster for that patch set — that one call
+ * waits for the measurement; RTMI_FF_KERNEL=path|flat in the environment forces one.
+ * rtmi_debug_form_factor_kernel: 0 = not measured yet, 1 = paths, 2 = root (diagnostic; no reference counterpart). */
+int rtmi_debug_form_factor_kernel(rtmi_patches *);
 int rtmi_form_factors_dev(rtmi_patches *, const double *light_center, uint32_t samples, uint32_t light_samples,
                           uint64_t seed, uint32_t flags, uint32_t row0, uint32_t n_rows, float *d_F, uint64_t ld,
                           void *stream);

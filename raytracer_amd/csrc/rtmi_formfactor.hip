@@ -29,6 +29,7 @@
 #include "rtmi_rad_device.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -688,39 +689,89 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 	if (ld < n) return fail(std::string(who) + ": ld < n");
 	hipStream_t st = (hipStream_t)stream;
 	const rtmi_scene *s = P->scene;
-	const char *mode = std::getenv("RTMI_FF_KERNEL");
-	if (mode && std::strcmp(mode, "flat") == 0) { // the round-1 kernel: every ray from the root (cross-check)
-		const uint64_t total = (uint64_t)n_rows * P->n, grid = (total + kBlock - 1) / kBlock;
+	// Two kernels give the same matrix bit for bit: the path walk (this file's header) and the root traversal of round 1.
+	// The first wins where the rays of a pair pass few other triangles (rooms: 37 against 10 G pair-samples/s on the 65 712-patch
+	// box), the second where every ray passes many (a furnished room, a statue seen from inside: 4.2 against 9.8 and 1.5 against
+	// 3.9) — there nearly every sibling box is met, each is entered on its own, and nothing is gained over walking front to back
+	// from the root.  Which one serves a patch set is MEASURED at its first sizeable call: both run on the call's first rows
+	// (up to 1024 of them; they are written more than once, same bits), HIP events time them, the faster stays (that one call waits for the events).
+	// RTMI_FF_KERNEL=path|flat forces one.
+	auto launch_flat = [&](uint32_t first, uint32_t count, float *out) -> int {
+		const uint64_t total = (uint64_t)count * P->n, grid = (total + kBlock - 1) / kBlock;
 		if (grid > 0x7fffffffull) return fail(std::string(who) + ": too many entries for one launch; shard the rows");
-		hipLaunchKernelGGL(k_form_factors_flat, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes_binary, st, s->dev, pdev(P), samples, seed, row0,
-		                   n_rows, d_F, ld);
-	} else {
-		try {
-			if (build_ff_tables(P, who)) return -1;
-		} catch (const std::exception &e) {
-			return fail(std::string(who) + ": building the path tables: " + e.what());
-		}
+		hipLaunchKernelGGL(k_form_factors_flat, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes_binary, st, s->dev, pdev(P), samples, seed, first,
+		                   count, out, ld);
+		return launch_check(who);
+	};
+	auto launch_path = [&](uint32_t first, uint32_t count, float *out) -> int {
 		uint32_t band = std::max(1u, env_uint("RTMI_FF_BAND", 64));
-		while ((n_rows + band - 1) / band > 4u * 65535u) band *= 2;
-		const FFTables T = {static_cast<const ChainEntry *>(P->d_chain), static_cast<const PatchMeta *>(P->d_meta), P->d_dfs, P->n_groups};
+		while ((count + band - 1) / band > 4u * 65535u) band *= 2;
 		// beam margin: the 1e-5 origin offset, the exact test's per-ray pad (<= 2^-17·absmax) and the fp32 roundings of both
 		const float margin = 1.52587890625e-05f * s->dev.absmax + 1e-4f;
-		const uint32_t n_bands = (n_rows + band - 1) / band;
+		const uint32_t n_bands = (count + band - 1) / band;
 		const dim3 grid((P->n_groups + 7u) / 8u * 8u, (n_bands + kBlock / 64 - 1) / (kBlock / 64));
 		// a lane's stack: up to pend_cap sibling subtrees waiting (more is rare: that ray starts over from the root) + the
 		// depth + 1 entries the traversal inside one of them can need
 		const uint32_t pend_cap = std::min(s->info.max_depth + 1u, std::max(1u, env_uint("RTMI_FF_PEND", 8)));
 		const uint32_t lds = (s->info.max_depth + 1u + pend_cap) * kBlock * (uint32_t)sizeof(int);
 		hipLaunchKernelGGL(k_form_factors, grid, dim3(kBlock), lds, st, s->dev, (const double *)P->d_verts, (const double *)P->d_normals,
-		                   (const double *)P->d_area, P->n, T.chain, T.meta, T.dfs, samples, seed, row0, n_rows, band, margin, pend_cap, P->n_groups, d_F, ld);
+		                   (const double *)P->d_area, P->n, static_cast<const ChainEntry *>(P->d_chain), static_cast<const PatchMeta *>(P->d_meta),
+		                   P->d_dfs, samples, seed, first, count, band, margin, pend_cap, P->n_groups, out, ld);
+		return launch_check(who);
+	};
+	int kernel = 0;
+	const char *mode = std::getenv("RTMI_FF_KERNEL");
+	if (mode && std::strcmp(mode, "flat") == 0) kernel = 2;
+	else if (mode && std::strcmp(mode, "path") == 0) kernel = 1;
+	if (kernel != 2) {
+		try {
+			if (build_ff_tables(P, who)) return -1;
+		} catch (const std::exception &e) {
+			return fail(std::string(who) + ": building the path tables: " + e.what());
+		}
 	}
-	if (launch_check(who)) return -1;
+	if (kernel == 0) {
+		std::lock_guard<std::mutex> lock(P->ff_mutex);
+		kernel = P->ff_kernel;
+		// rows that reach patch rows only (the light's row is zero work), enough of them for a stable time
+		const uint32_t rows_p = row0 < P->n ? std::min(n_rows, P->n - row0) : 0u;
+		// At least 256 rows (four bands: every wave of the path walk's workgroups has work), up to 1024: the path walk's
+		// workgroups differ a lot in length (a 256-row launch is one round of them and ends with its slowest: 14-20 ms on the
+		// box where 4096 rows take 72), so a short sample flatters the root traversal; 1024 rows are four rounds.
+		if (kernel == 0 && P->n >= 1024 && rows_p >= 256) {
+			const uint32_t cal = std::min(rows_p, 1024u);
+			hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+			bool ok = hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess && hipEventCreate(&ev[2]) == hipSuccess;
+			float t_path = 0.f, t_flat = 0.f;
+			// (an untimed run first: after idle time the first long kernel runs at clocks that are still ramping up)
+			ok = ok && launch_path(row0, cal, d_F) == 0;
+			ok = ok && hipEventRecord(ev[0], st) == hipSuccess && launch_path(row0, cal, d_F) == 0 && hipEventRecord(ev[1], st) == hipSuccess &&
+			     launch_flat(row0, cal, d_F) == 0 && hipEventRecord(ev[2], st) == hipSuccess && hipEventSynchronize(ev[2]) == hipSuccess &&
+			     hipEventElapsedTime(&t_path, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&t_flat, ev[1], ev[2]) == hipSuccess;
+			for (hipEvent_t e : ev)
+				if (e) (void)hipEventDestroy(e);
+			if (!ok) return fail(std::string(who) + ": timing the two form-factor kernels failed: " + hipGetErrorString(hipGetLastError()));
+			kernel = P->ff_kernel = (t_flat * 1.1f < t_path) ? 2 : 1;
+			if (env_uint("RTMI_VERBOSE", 0))
+				std::fprintf(stderr, "%s: %u rows: path walk %.3f ms, root traversal %.3f ms -> %s\n", who, cal, t_path, t_flat,
+				             kernel == 1 ? "path walk" : "root traversal");
+		}
+		if (kernel == 0) kernel = 1; // small patch sets and small first calls: the path walk, not remembered
+	}
+	if ((kernel == 2 ? launch_flat(row0, n_rows, d_F) : launch_path(row0, n_rows, d_F)) != 0) return -1;
 	if (light_center) {
 		hipLaunchKernelGGL(k_ff_light_column, dim3((n_rows + kBlock - 1) / kBlock), dim3(kBlock), s->stack_bytes_binary, st, s->dev, pdev(P),
 		                   light_center[0], light_center[1], light_center[2], light_samples, seed, flags, row0, n_rows, d_F, ld);
 		if (launch_check(who)) return -1;
 	}
 	return 0;
+}
+
+// 0 = not measured yet, 1 = path walk, 2 = root traversal (see rtmi_form_factors_dev)
+int rtmi_debug_form_factor_kernel(rtmi_patches *P) {
+	if (check_patches(P, "rtmi_debug_form_factor_kernel")) return -1;
+	std::lock_guard<std::mutex> lock(P->ff_mutex);
+	return P->ff_kernel;
 }
 
 #ifdef RTMI_FF_COUNT

@@ -18,6 +18,7 @@ struct rtmi_patches {
 	// tables of the form-factor kernel (rtmi_formfactor.hip), built on the first rtmi_form_factors_dev call
 	std::mutex ff_mutex;
 	bool ff_ready = false;
+	int ff_kernel = 0; // which form-factor kernel serves this patch set: 0 = not measured yet, 1 = path walk, 2 = root traversal (ff_mutex)
 	void *d_chain = nullptr;   // ChainEntry[]: per patch, the siblings along its root-to-leaf path
 	void *d_meta = nullptr;    // PatchMeta[n]
 	uint32_t *d_dfs = nullptr; // patch ids in depth-first leaf order, padded with RTMI_MISS to a multiple of 64

@@ -170,6 +170,7 @@ def test_c5_form_factor_rows_of_the_64k_box_equal_the_oracle(rt, oracle):
     blk = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=20480, n_rows=4096).cpu().numpy()
     one = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=21000, n_rows=1).cpu().numpy()[0]
     assert np.array_equal(blk[21000 - 20480], one)
+    assert rt.lib.rtmi_debug_form_factor_kernel(rad.handle) == 1        # measured on that call's first rows: in a room the path walk wins
     scene.check()
 
 

@@ -10,11 +10,15 @@ from raytracer_amd import workloads
 torch.cuda.set_device(0)
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 74
-verts, normals, light = workloads.closed_box(k)
+if len(sys.argv) > 3:    # a scene file of tests/golden/scenes instead of the box (lenient reader), e.g. real_full_room
+    sc = rt.BuildScene(os.path.join(ROOT, "tests", "golden", "scenes"), sys.argv[3], lenient=True)
+    verts, normals = sc["tris"], (-sc["normals"] if sys.argv[3] == "real_buddha" else sc["normals"])
+else:
+    verts, normals, light = workloads.closed_box(k)
 box = rt.Scene(verts)
 rad = rad = rt.Radiosity(box, normals, None)
 out = (C.c_uint64 * 96)()
-rad.findFormFactor(samples=10, seed=1, row0=1000, n_rows=rows)
+rad.findFormFactor(samples=10, seed=1, row0=1000 if len(sys.argv) <= 3 else 0, n_rows=rows)
 torch.cuda.synchronize()
 rt.lib.rtmi_debug_ff_counts(out)
 c = list(out)

@@ -11,7 +11,7 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 74
 verts, normals, light = workloads.closed_box(k)
 box = rt.Scene(verts)
 rad = rt.Radiosity(box, normals, light)
-rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=1000, n_rows=8)
+rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=1000, n_rows=1024)   # warm-up; the library times its two kernels here
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 F = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=1000, n_rows=rows)
