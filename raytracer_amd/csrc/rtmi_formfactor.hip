@@ -451,9 +451,12 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 	}
 }
 
+#ifndef RTMI_FF_FLAT_WAVES
+#define RTMI_FF_FLAT_WAVES 7
+#endif
 // ---- the round-1 kernel, kept as a cross-check (RTMI_FF_KERNEL=flat; tests compare the two) -----------------------------
 // One lane per matrix entry (i, j), j fastest; every ray descends from the root.
-RTMI_TRAVERSAL_KERNEL_W(7) void k_form_factors_flat(SceneDev S, PatchesDev P, uint32_t samples, uint64_t seed, uint32_t row0,
+RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_FLAT_WAVES) void k_form_factors_flat(SceneDev S, PatchesDev P, uint32_t samples, uint64_t seed, uint32_t row0,
                                                     uint32_t n_rows, float *__restrict__ F, uint64_t ld) {
 	extern __shared__ int stack_all[];
 	int *stack = stack_all + threadIdx.x;
