@@ -119,7 +119,7 @@ int rtmi_radiosity_solve_sharded_dev(rtmi_comm *c, const float *d_F, uint64_t ld
                                      const double rho[3], const float *d_E, float *d_B, float tol_rel, uint32_t max_sweeps,
                                      uint32_t check_every, rtmi_solve_stats *stats, void *stream) {
 	const char *who = "rtmi_radiosity_solve_sharded_dev";
-	if (!c || !d_F || !rho || !d_E || !d_B) return fail(std::string(who) + ": NULL argument");
+	if (!c || (!d_F && n_rows) || !rho || !d_E || !d_B) return fail(std::string(who) + ": NULL argument"); // (a rank may own no rows)
 	if (n == 0) return fail(std::string(who) + ": n == 0");
 	int dev = -1;
 	if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return fail(std::string(who) + ": the communicator was created on another device");
