@@ -437,7 +437,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 					const D3 n = d3(np[0], np[1], np[2]);
 					const D3 v1 = d3(Th.v0[0], Th.v0[1], Th.v0[2]);
 					const D3 p = org + (dot(v1 - org, n) * dir) / dot(n, dir);
-					if (sqrt(len2(p - xj)) < kEpsilon) {
+					if (len2(p - xj) < kEpsilonSquaredExact) { // sqrt(...) < 1e-5 exactly (rtmi_rad_device.hpp)
 						const double cosFactor = c1 * c2;
 						const double delF = cosFactor / ((kPi * dist2) + area_term);
 						if (delF > 0.0) ff += delF;

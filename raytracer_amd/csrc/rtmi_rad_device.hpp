@@ -30,6 +30,11 @@ struct rtmi_patches {
 namespace rtmi {
 
 constexpr double kEpsilon = 1.0e-5;       // Render2/base.h:57
+// The reference's visibility test is Length(p − xj) < 1e-5 (radiosity.cpp:249).  The square root is correctly rounded and
+// monotone, so sqrt(x) < 1e-5 holds exactly for the doubles x below the least x whose root rounds to >= 1e-5 — this constant
+// (one ulp below fl(1e-5·1e-5); tests/test_host_abi.py checks both neighbours with the host's sqrt).  Comparing the squared
+// length with it gives the same verdict bit for bit and saves a double-precision square root per ray.
+constexpr double kEpsilonSquaredExact = 0x1.b7cdfd9d7bdbbp-34;
 constexpr double kPi = 3.14159265358979;  // Render2/base.h:52
 constexpr uint32_t kLightStream = 0xFFFFFFFFu;
 
@@ -100,7 +105,7 @@ __device__ __forceinline__ bool visible_along(const SceneDev &S, const PatchesDe
 	const D3 v1 = d3(T.v0[0], T.v0[1], T.v0[2]);
 	const D3 p = org + (dot(v1 - org, n) * dir) / dot(n, dir);
 	const double *nj = P.normals + 3 * (size_t)j;
-	return sqrt(len2(p - yi)) < kEpsilon && dot(dir, d3(nj[0], nj[1], nj[2])) < 0;
+	return len2(p - yi) < kEpsilonSquaredExact && dot(dir, d3(nj[0], nj[1], nj[2])) < 0; // sqrt(...) < 1e-5, see kEpsilonSquaredExact
 }
 __device__ __forceinline__ bool visible(const SceneDev &S, const PatchesDev &P, uint32_t j, D3 xi, D3 yi, int *stack) {
 	const D3 dir = unit(yi - xi);

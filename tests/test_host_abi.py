@@ -221,6 +221,23 @@ def test_lenient_reader_takes_what_the_references_reader_cannot(tmp_path):
         rt.BuildScene(str(tmp_path), "gone", lenient=True)
 
 
+def test_squared_visibility_threshold_is_exact():
+    """rtmi_rad_device.hpp compares |p − xj|² with kEpsilonSquaredExact instead of sqrt(|p − xj|²) with 1e-5 (radiosity.cpp:249):
+    the constant must be the least double whose correctly rounded root is >= 1e-5, then the two tests agree on every double."""
+    import math
+    src = open(os.path.join(ROOT, "raytracer_amd", "csrc", "rtmi_rad_device.hpp")).read()
+    T = float.fromhex(re.search(r"kEpsilonSquaredExact = (0x[0-9a-fp.+-]+);", src).group(1))
+    assert math.sqrt(T) >= 1e-5 and math.sqrt(math.nextafter(T, 0.0)) < 1e-5
+    x = T                                              # and monotone around it, a few thousand neighbours each way
+    for _ in range(4000):
+        x = math.nextafter(x, math.inf)
+        assert math.sqrt(x) >= 1e-5
+    x = T
+    for _ in range(4000):
+        x = math.nextafter(x, 0.0)
+        assert math.sqrt(x) < 1e-5
+
+
 def test_header_is_plain_c(tmp_path):
     """include/rtmi.h is the boundary a C, C++, cgo or ctypes host binds: it must compile as C99 and as C++17 with nothing
     else included, and a C program using its structs must link against librtmi.so."""
