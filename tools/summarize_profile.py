@@ -14,7 +14,7 @@ from collections import defaultdict
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
-KERNELS = ["k_jacobi_sweep", "k_primary_closest", "k_form_factors", "k_primary_work", "k_trace_rays"]
+KERNELS = ["k_jacobi_sweep", "k_primary_closest", "k_form_factors_flat", "k_form_factors", "k_primary_work", "k_trace_rays"]   # (the longer name before its prefix)
 
 
 def short(name):
