@@ -10,7 +10,13 @@ from raytracer_amd import workloads
 torch.cuda.set_device(0)
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 74
-if len(sys.argv) > 3:    # a scene file of tests/golden/scenes instead of the box (lenient reader), e.g. real_full_room
+if len(sys.argv) > 3 and sys.argv[3] == "mixed":     # the furnished room of tools/quick_ff_mixed.py
+    vb, nb, _ = workloads.closed_box(k)
+    fv = np.concatenate([workloads._box((1.0, 1.0, 0.0), (3.5, 2.5, 1.2), 24), workloads._box((6.0, 0.2, 0.0), (9.5, 1.5, 6.0), 32),
+                         workloads._box((0.3, 5.0, 0.0), (2.8, 9.5, 1.0), 28), workloads._box((7.0, 7.0, 2.0), (9.8, 9.8, 2.3), 20),
+                         workloads._box((4.2, 4.2, 0.0), (5.6, 5.6, 3.0), 20)])
+    verts, normals = np.concatenate([vb, fv]), np.concatenate([nb, workloads.face_normals(fv)])
+elif len(sys.argv) > 3:    # a scene file of tests/golden/scenes instead of the box (lenient reader), e.g. real_full_room
     sc = rt.BuildScene(os.path.join(ROOT, "tests", "golden", "scenes"), sys.argv[3], lenient=True)
     verts, normals = sc["tris"], (-sc["normals"] if sys.argv[3] == "real_buddha" else sc["normals"])
 else:
@@ -18,7 +24,7 @@ else:
 box = rt.Scene(verts)
 rad = rad = rt.Radiosity(box, normals, None)
 out = (C.c_uint64 * 96)()
-rad.findFormFactor(samples=10, seed=1, row0=1000 if len(sys.argv) <= 3 else 0, n_rows=rows)
+rad.findFormFactor(samples=10, seed=1, row0=(20000 if len(sys.argv) > 3 and sys.argv[3] == 'mixed' else 1000 if len(sys.argv) <= 3 else 0), n_rows=rows)
 torch.cuda.synchronize()
 rt.lib.rtmi_debug_ff_counts(out)
 c = list(out)
