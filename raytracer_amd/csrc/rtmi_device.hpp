@@ -51,7 +51,7 @@ constexpr int kBlock = 256;       // threads per workgroup in every traversal ke
 constexpr int kSentinel = INT32_MIN;      // lane state: no node left (ray finished, or lane idle)
 constexpr uint32_t kGuard = 1u << 26;      // default of SceneDev::guard: wave-iterations per ray after which a traversal gives up (safety net)
 #ifndef RTMI_NODE_STEPS
-#define RTMI_NODE_STEPS 3
+#define RTMI_NODE_STEPS 4
 #endif
 constexpr int kNodeSteps = RTMI_NODE_STEPS;  // node steps a wave takes per scheduling round of trace_queue
 constexpr uint32_t kQueueChunk = 256;     // items a wave takes from the launch's queue at a time (4 squares of 8x8 pixels) ...
