@@ -268,8 +268,6 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 	const D3 nj = d3(P.normals[3 * (size_t)jj], P.normals[3 * (size_t)jj + 1], P.normals[3 * (size_t)jj + 2]);
 	const double area_j = P.area[jj];
 	const double area_term = area_j / (int)samples; // :319, the same for every sample
-	float blo[3], bhi[3];
-	patch_bounds(ejp, blo, bhi);
 	const ChainEntry *chain_j = T.chain + mj.chain_off;
 	const ChainEntry *chain_0 = T.chain + m0.chain_off;
 	// The group's paths agree on their first `common` levels: those siblings are the same for every lane (read once per wave
@@ -300,8 +298,13 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 			const uint32_t lca = (pair && xij) ? (uint32_t)(__ffs((int)xij) - 1) : 0u;     // first level where the paths part
 			const uint32_t lca0 = xi0 ? (uint32_t)(__ffs((int)xi0) - 1) : 32u;              // ... for the group's first patch (uniform)
 			{
-				float alo[3], ahi[3];
+				float alo[3], ahi[3], blo[3], bhi[3];
 				patch_bounds(ei, alo, ahi);
+				// (patch j's bounds again for every row, through an index the compiler cannot match with `jj`: 9 loads and
+				// ≈ 40 instructions per pair against six registers held over the whole kernel, one of them spilled)
+				uint32_t jb = jj;
+				asm volatile("" : "+v"(jb));
+				patch_bounds(P.verts + 9 * (size_t)jb, blo, bhi);
 				const float cax = 0.5f * (alo[0] + ahi[0]), cay = 0.5f * (alo[1] + ahi[1]), caz = 0.5f * (alo[2] + ahi[2]);
 				const float cbx = 0.5f * (blo[0] + bhi[0]), cby = 0.5f * (blo[1] + bhi[1]), cbz = 0.5f * (blo[2] + bhi[2]);
 				const float px = fmaxf(ahi[0] - alo[0], bhi[0] - blo[0]) * 0.5f + margin;
@@ -445,9 +448,17 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				}
 			}
 			ff = ff / ((double)samples);
-			out = ff * area_j;
+			// (area_j read again, through an index the compiler cannot match with line 269's: kept in registers over the row
+			// it was the one value the kernel spilled.)
+			uint32_t jr = jj;
+			asm volatile("" : "+v"(jr));
+			out = ff * P.area[jr];
 		}
-		if (valid_j) F[(uint64_t)r * ld + j] = (float)out;
+		if (valid_j) {
+			uint32_t js = j; // (likewise: the hoisted address F + 4 j was spilled; the index costs one register, not two)
+			asm volatile("" : "+v"(js));
+			F[(uint64_t)r * ld + js] = (float)out;
+		}
 	}
 }
 
