@@ -226,10 +226,11 @@ RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx
 	F[(uint64_t)r * ld + P.n] = (float)out; // the light's own entry (:382) is 0
 }
 
-// 4 waves per SIMD: 128 registers, three values spilled (16 B of scratch per lane, stored once per kernel / once per row,
-// nothing inside the sample loop).  The kernel issues vector instructions in only 0.6 of the cycles at 3 waves (133
-// registers, no spill) — dependent double-precision chains — so the fourth wave pays: 34.2 -> 37.7 G pair-samples/s on the
-// 65 712-patch box; 5 waves (96 registers, 35 spills) 31.4.
+// 4 waves per SIMD: 124 of 128 registers, no scratch (what depends on j alone and is needed once per row — the store address,
+// the area, the patch's bounds — is computed again per row through laundered indices instead of being held over the kernel;
+// held, three of those values were spilled).  The kernel issues vector instructions in only 0.6 of the cycles at 3 waves
+// — dependent double-precision chains — so the fourth wave pays: 34.2 -> 38.2 G pair-samples/s on the 65 712-patch box;
+// 5 waves (96 registers, 35 spills) 31.4.
 #ifndef RTMI_FF_WAVES
 #define RTMI_FF_WAVES 4
 #endif
