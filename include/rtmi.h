@@ -322,7 +322,9 @@ int rtmi_visible_points(rtmi_patches *, uint64_t m, const int32_t *ej, const dou
  * Two kernels compute the same matrix bit for bit: one follows the two patches' paths through the hierarchy
  * (fast in rooms), one descends from the root (fast in clutter).  The first call on a patch set that covers at least 256 patch
  * rows of at least 1024 patches times both on its first rows (up to 1024) and keeps the faster for that patch set — that one call
- * waits for the measurement; RTMI_FF_KERNEL=path|flat in the environment forces one.
+ * waits for the measurement; RTMI_FF_KERNEL=path|flat in the environment forces one.  A call whose stream is being captured
+ * into a graph measures nothing (it takes what an earlier call settled, else the path kernel); the per-patch-set tables of the
+ * path kernel are built (hipMalloc, copies) by the FIRST call that uses it, so make one call outside the capture first.
  * rtmi_debug_form_factor_kernel: 0 = not measured yet, 1 = paths, 2 = root (diagnostic; no reference counterpart). */
 int rtmi_debug_form_factor_kernel(rtmi_patches *);
 int rtmi_form_factors_dev(rtmi_patches *, const double *light_center, uint32_t samples, uint32_t light_samples,

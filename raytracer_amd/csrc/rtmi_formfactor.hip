@@ -753,7 +753,11 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		// At least 256 rows (four bands: every wave of the path walk's workgroups has work), up to 1024: the path walk's
 		// workgroups differ a lot in length (a 256-row launch is one round of them and ends with its slowest: 14-20 ms on the
 		// box where 4096 rows take 72), so a short sample flatters the root traversal; 1024 rows are four rounds.
-		if (kernel == 0 && P->n >= 1024 && rows_p >= 256) {
+		// (not while the stream is being captured into a graph: the measurement waits for events, which a capture forbids —
+		// such a call takes the path walk, or what an earlier call or RTMI_FF_KERNEL settled)
+		hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+		const bool capturing = hipStreamIsCapturing(st, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone;
+		if (kernel == 0 && !capturing && P->n >= 1024 && rows_p >= 256) {
 			const uint32_t cal = std::min(rows_p, 1024u);
 			hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 			bool ok = hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess && hipEventCreate(&ev[2]) == hipSuccess;

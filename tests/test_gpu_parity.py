@@ -316,6 +316,38 @@ def test_form_factors_on_the_references_meshes(rt, oracle, monkeypatch, stem, ro
     assert np.array_equal(F_auto.view(np.uint32), F_path.view(np.uint32))
 
 
+def test_form_factors_inside_a_graph_capture(rt):
+    """A caller that captures its launches into a graph (torch.cuda.graph = hipStreamBeginCapture on the stream): a
+    form-factor call of measurable size neither times the two kernels (that waits for events, which a capture
+    forbids) nor allocates — the path tables exist since the first, uncaptured call — and the replayed graph writes
+    the same bits as a plain call."""
+    import torch
+    from raytracer_amd import workloads
+    verts, normals, _ = workloads.closed_box(16)      # 3072 patches
+    n = len(verts)
+    assert n >= 1024
+    scene = rt.Scene(verts)
+    rad = rt.Radiosity(scene, normals, None)
+    plain = rad.findFormFactor(samples=4, seed=9, row0=0, n_rows=8).clone()       # builds the tables; too small to measure on
+    ld = rad.ld
+    out = torch.zeros((512, ld), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        rc = rt.lib.rtmi_form_factors_dev(rad.handle, None, 4, 30, 9, 0, 0, 512, out.data_ptr(), ld, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rt.lib.rtmi_last_error().decode()
+    assert rt.lib.rtmi_debug_form_factor_kernel(rad.handle) == 0                   # nothing was measured
+    assert float(out.abs().sum()) == 0.0                                            # captured, not run
+    graph.replay()
+    torch.cuda.synchronize()
+    want = rad.findFormFactor(samples=4, seed=9, row0=0, n_rows=512)                # a plain call (this one measures)
+    assert rt.lib.rtmi_debug_form_factor_kernel(rad.handle) in (1, 2)
+    assert torch.equal(out.view(torch.int32), want.view(torch.int32))
+    assert torch.equal(out[:8].view(torch.int32), plain.view(torch.int32))
+    scene.check()
+
+
 def test_patches_must_be_the_scenes_triangles(rt):
     from raytracer_amd import workloads
     v = workloads.soup(50, seed=2, edge=0.3)
