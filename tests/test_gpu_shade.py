@@ -264,6 +264,39 @@ def test_the_references_large_assets_render(rt, oracle, stem, n_tris):
     assert len(np.unique(pix.reshape(-1, 3), axis=0)) > 200                                # a picture, not a constant
 
 
+def test_frame_and_ray_queries_inside_a_graph_capture(rt):
+    """Every stage of the frame path is a launch whose ray count lives in device memory, and the ray queries reset
+    their queue with a memset on the stream: both can be captured into a graph (torch.cuda.graph) once a first,
+    uncaptured call has sized the workspace, and the replayed graph gives the plain calls' bits."""
+    import torch
+    g = load_golden("g6_shade_studio.npz")
+    scene, sh = _shader(rt, g, "mats_amb", max_tree_depth=3, ao_rays=10, seed=5)
+    cam = rt.Camera.from_cam14(g["cam14"], g["res"])
+    n = cam.x_res * cam.y_res
+    rgb, pix = sh.Rasterize(cam)                                  # plain call: the workspace exists from here on
+    d_rgb = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    d_pix = torch.zeros(n, 3, dtype=torch.uint8, device="cuda")
+    d_hits = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+    d_plain = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+    scene.primary_dev(cam, d_plain.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        st = torch.cuda.current_stream().cuda_stream
+        scene.primary_dev(cam, d_hits.data_ptr(), stream=st)
+        sh.render_frame_dev(cam, d_rgb.data_ptr(), d_pix.data_ptr(), stream=st)
+    assert int(d_pix.sum()) == 0 and int(d_hits.sum()) == 0      # captured, not run
+    for _ in range(2):
+        d_rgb.zero_(); d_pix.zero_(); d_hits.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(d_rgb.cpu().numpy().reshape(rgb.shape), rgb)
+        assert np.array_equal(d_pix.cpu().numpy().reshape(pix.shape), pix)
+        assert torch.equal(d_hits, d_plain)
+    scene.check()
+
+
 def test_shader_errors(rt):
     g = load_golden("g6_shade_studio.npz")
     scene = rt.Scene(g["tris"], g["tri_obj"])
