@@ -367,10 +367,19 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	for (uint64_t i = 0; i < 9 * n; ++i)
 		if (!std::isfinite(xyz[i])) { fail("rtmi_scene_create: non-finite vertex coordinate"); return nullptr; }
 	auto t0 = std::chrono::steady_clock::now();
+	// RTMI_VERBOSE=1: seconds per phase of the build on stderr
+	const bool verbose = env_uint("RTMI_VERBOSE", 0) != 0;
+	auto t_phase = t0;
+	auto phase = [&](const char *what) {
+		const auto now = std::chrono::steady_clock::now();
+		if (verbose) std::fprintf(stderr, "rtmi_scene_create: %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_phase).count());
+		t_phase = now;
+	};
 	const unsigned leaf = 1; // the 4-wide nodes address a leaf child as ONE triangle (rtmi_device.hpp, WNode)
 	const unsigned threads = std::min(env_uint("RTMI_BUILD_THREADS", std::max(1u, std::thread::hardware_concurrency())), 16u);
 	Bvh2 bvh = build_bvh2(xyz, n, leaf, kStackDepth - 2, threads);
 	if (n > 0 && bvh.depth > (uint32_t)kStackDepth - 1) { fail("rtmi_scene_create: BVH deeper than the traversal stack"); return nullptr; }
+	phase("binary hierarchy (SAH)");
 
 	rtmi_scene *s = new rtmi_scene();
 	s->n_tris = n;
@@ -411,6 +420,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	// binary hierarchy (display pass): one push per inner node on a root-to-leaf path at most; the 4-wide one may need more
 	s->stack_bytes = s->stack_bytes_binary = (bvh.depth + 1u) * kBlock * (uint32_t)sizeof(int);
 	if (n == 0) return s;
+	phase("hash, device set-up");
 
 	// ---- the 4-wide hierarchy of the ray queries: collapse, lay out, quantise (bvh_build.cpp: build_wide) ----------
 	Wide4 wide;
@@ -418,13 +428,14 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		std::string err;
 		if (build_wide(bvh, wide, err, threads)) { (void)hipHostFree(s->h_error); (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: " + err); return nullptr; }
 	}
+	phase("4-wide hierarchy");
 	static_assert(sizeof(WideNode) == sizeof(WNode), "host and device layout of the 4-wide node");
 	const std::vector<uint32_t> &leaf_pos = wide.leaf_pos;
 	const std::vector<WideNode> &wnodes = wide.nodes;
 	const uint32_t wide_need = wide.stack_need;
 	if ((wide_need + 1u) * kBlock * sizeof(int) > 64u * 1024u) { (void)hipHostFree(s->h_error); (void)hipFree(s->d_queue); delete s; fail("rtmi_scene_create: BVH deeper than the traversal stack"); return nullptr; }
 	s->stack_bytes = (std::max(bvh.depth, wide_need) + 1u) * kBlock * (uint32_t)sizeof(int);
-	if (env_uint("RTMI_VERBOSE", 0))
+	if (verbose)
 		std::fprintf(stderr, "rtmi_scene_create: %zu binary nodes of depth %u, %zu 4-wide nodes needing %u stack entries, %u B of LDS per workgroup\n",
 		             bvh.nodes.size(), bvh.depth, wnodes.size(), wide_need, s->stack_bytes);
 
@@ -444,6 +455,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		T.orig = id;
 		T.object = obj ? obj[id] : 0u;
 	}
+	phase("leaf-ordered triangles");
 	// ---- the binary nodes of the display pass: depth-first order (a node's near subtree follows it in memory)
 	auto ref_of_leaf = [&](int32_t build_id) { return (int32_t) ~(leaf_pos[build_id] << 3); };
 	// the 16-bit grid over the scene bounds: plane = qlo + q·qstep, evaluated by the kernels in fp32.  qstep is
@@ -501,6 +513,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		}
 		root_ref = 0;
 	}
+	phase("binary display nodes");
 	float absmax = 0.f;
 	for (int a = 0; a < 3; ++a) absmax = std::max(absmax, std::max(std::fabs(bvh.lo[a]), std::fabs(bvh.hi[a])));
 
@@ -525,7 +538,16 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	}
 	bool ok = true;
 	if (!nodes.empty()) ok = ok && hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(QNode), hipMemcpyHostToDevice) == hipSuccess;
-	if (!wnodes.empty()) ok = ok && hipMemcpy2D(d_wnodes, kNodeStride, wnodes.data(), sizeof(WNode), sizeof(WNode), wnodes.size(), hipMemcpyHostToDevice) == hipSuccess;
+	if (!wnodes.empty()) {
+		// (one plain copy: hipMemcpy2D moved these 48-byte rows one by one — 4.6 s of a 5.3 s scene build at 1 M triangles)
+		if (kNodeStride == sizeof(WNode)) {
+			ok = ok && hipMemcpy(d_wnodes, wnodes.data(), wnodes.size() * sizeof(WNode), hipMemcpyHostToDevice) == hipSuccess;
+		} else { // the padded layout of the RTMI_NODE_STRIDE experiment
+			std::vector<unsigned char> padded(wnodes.size() * (size_t)kNodeStride, 0);
+			for (size_t i = 0; i < wnodes.size(); ++i) std::memcpy(padded.data() + i * (size_t)kNodeStride, &wnodes[i], sizeof(WNode));
+			ok = ok && hipMemcpy(d_wnodes, padded.data(), padded.size(), hipMemcpyHostToDevice) == hipSuccess;
+		}
+	}
 	ok = ok && hipMemcpy(d_tris, tris.data(), tb, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(s->d_v1_orig, v1.data(), v1.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
 	if (!ok) {
@@ -534,6 +556,7 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		fail("rtmi_scene_create: upload failed");
 		return nullptr;
 	}
+	phase("device allocation and upload");
 	s->dev.n_top = wide.n_top;
 	s->dev.nodes = d_nodes; s->dev.wnodes = d_wnodes; s->dev.tris = d_tris; s->dev.root_ref = root_ref; s->dev.absmax = absmax;
 	for (int a = 0; a < 3; ++a) { s->dev.qlo[a] = qlo[a]; s->dev.qstep[a] = qstep[a]; }
