@@ -410,7 +410,6 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 	if (hipHostMalloc((void **)&s->h_error, sizeof(int), hipHostMallocMapped) != hipSuccess ||
 	    hipHostGetDevicePointer((void **)&s->dev.error, s->h_error, 0) != hipSuccess) {
 		if (s->h_error) (void)hipHostFree(s->h_error);
-	if (s->h_small) (void)hipHostFree(s->h_small);
 		(void)hipFree(s->d_queue);
 		delete s;
 		fail("rtmi_scene_create: hipHostMalloc failed");
@@ -807,6 +806,7 @@ void rtmi_scene_destroy(rtmi_scene *s) {
 	if (s->d_v1_orig) (void)hipFree(s->d_v1_orig);
 	if (s->d_queue) (void)hipFree(s->d_queue);
 	if (s->h_error) (void)hipHostFree(s->h_error);
+	if (s->h_small) (void)hipHostFree(s->h_small); // the small-batch buffer of the host-pointer calls (trace_host)
 	delete s;
 }
 
