@@ -83,7 +83,8 @@ __device__ __forceinline__ bool slab_box(const float4 a, const float4 b, const R
 // Work counters of the form-factor kernel (diagnostic builds only: make EXTRA=-DRTMI_FF_COUNT; tools/ff_counts.py)
 #ifdef RTMI_FF_COUNT
 __device__ unsigned long long g_ff_counts[96];
-#define FF_COUNT(k, n) do { if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&g_ff_counts[k], (unsigned long long)(n)); } while (0)
+// (n is evaluated by every active lane BEFORE the election: a ballot inside the elected lane's branch would see that lane alone)
+#define FF_COUNT(k, n) do { const unsigned long long n_ = (unsigned long long)(n); if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&g_ff_counts[k], n_); } while (0)
 #define FF_COUNT_LANES(k, pred) FF_COUNT(k, __popcll(__ballot(pred)))
 #else
 #define FF_COUNT(k, n) do { } while (0)
@@ -155,7 +156,8 @@ __device__ __forceinline__ void patch_bounds(const double *v, float lo[3], float
 // kSentinel) and `sp` entries on its stack.  Closest hit with the tie rule; vote-scheduled like trace(): per iteration the
 // wave takes ONE node step or ONE triangle step.
 __device__ __forceinline__ void trace_from(const SceneDev &S, const RayF &rf, double ox, double oy, double oz, double dx, double dy, double dz,
-                                           double &best, uint32_t &pos, int cur, int sp, int *stack) {
+                                           double &best, uint32_t &pos, int cur, int sp, int *stack, uint32_t tag = 0u) {
+	(void)tag; // diagnostic builds: which kind of call the steps are counted under
 	float tbest = f32_above(best);
 	uint32_t tk = 0, tend = 0;
 	for (uint32_t guard = 0;; ++guard) {
@@ -169,10 +171,10 @@ __device__ __forceinline__ void trace_from(const SceneDev &S, const RayF &rf, do
 		const int n_node = __popcll(__ballot(cur >= 0)), n_leaf = __popcll(__ballot(cur == kLeaf));
 		if (n_node + n_leaf == 0) break;
 		if (n_node >= n_leaf) {
-			FF_COUNT(6, 1); FF_COUNT(11, n_node);
+			FF_COUNT(6, 1); FF_COUNT(11, n_node); FF_COUNT(74 + tag, 1);
 			if (cur >= 0) cur = node_step(S, rf, tbest, cur, sp, stack);
 		} else if (cur == kLeaf) {
-			FF_COUNT(7, 1); FF_COUNT(12, n_leaf);
+			FF_COUNT(7, 1); FF_COUNT(12, n_leaf); FF_COUNT(76 + tag, 1);
 			const GTri T = load_tri(S.tris + tk);
 			double u = 0.0, v = 0.0;
 			const double t = mt_exact(ox, oy, oz, dx, dy, dz, T, u, v);
@@ -244,7 +246,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
                                                            const double *__restrict__ p_area, uint32_t p_n, const ChainEntry *__restrict__ t_chain,
                                                            const PatchMeta *__restrict__ t_meta, const uint32_t *__restrict__ t_dfs,
                                                            uint32_t samples, uint64_t seed, uint32_t row0, uint32_t n_rows, uint32_t band_rows,
-                                                           float margin, uint32_t pend_cap, uint32_t n_groups, float *__restrict__ F, uint64_t ld) {
+                                                           float margin, double graze_cos, uint32_t pend_cap, uint32_t n_groups, float *__restrict__ F, uint64_t ld) {
 	struct { const double *verts, *normals, *area; uint32_t n; } P = {p_verts, p_normals, p_area, p_n};
 	struct { const ChainEntry *chain; const PatchMeta *meta; const uint32_t *dfs; } T = {t_chain, t_meta, t_dfs};
 	extern __shared__ int stack_all[];
@@ -291,9 +293,12 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 			// boxes' centres.  `margin` covers the 1e-5, the per-ray pad of the exact test and all fp32 roundings.
 			// mask_i / mask_j: bit L = the sibling at level L of path i / path j may be met by a ray of this pair.
 			// *_front: without the siblings that lie wholly behind (or in) the patch's own plane — flagged on the host, in
-			// double, from exact bounds (build_ff_tables).  A ray that leaves patch i with cos > 1e-3 rises above that plane
-			// at once, so it meets such triangles only at t <= −1e-5/2 < 0; one that arrives on j with cos > 1e-3 meets them
-			// no earlier than 2.5e-6 before its hit on j, where every hit gives the same verdict as the hit on j itself.
+			// double, from exact bounds (build_ff_tables: nothing of the sibling is more than delta above the plane).  With
+			// graze_cos = 1.6e6·delta (host; 1.6e-5 in a room of size 10): a ray that leaves patch i with cos > graze_cos is
+			// 1e-5·cos > 16·delta above that plane at its origin and rises, so it meets such triangles only at t < 0; one that
+			// arrives on j with cos > graze_cos is delta above j's plane no earlier than delta/cos < 6.3e-7 before its hit on j,
+			// so it meets them no earlier than that — where every hit gives the verdict the hit on j gives (|p − xj| < 1e-5
+			// with a factor 16 to spare for the roundings of t and p, which are of relative size 1e-15/cos).
 			uint32_t mask_i = 0u, mask_j = 0u, front_i = 0u, front_j = 0u;
 			const uint32_t xij = mi.path ^ mj.path, xi0 = mi.path ^ m0.path;
 			const uint32_t lca = (pair && xij) ? (uint32_t)(__ffs((int)xij) - 1) : 0u;     // first level where the paths part
@@ -398,7 +403,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				// Triangle i lies 1e-5 BEHIND the origin along the ray (t = −1e-5 up to rounding of relative size 1e-15/c1): it
 				// cannot be hit unless the ray all but grazes it — then it is tested like any other, and so is everything
 				// behind the two planes.
-				const bool graze = !(c1 > 1e-3 && c2 > 1e-3);
+				const bool graze = !(c1 > graze_cos && c2 > graze_cos);
 				if (walk && (graze || S.absmax > 1e4f)) push((int)~(mi.leafpos << 3));
 				const uint32_t s_i = graze ? mask_i : front_i, s_j = graze ? mask_j : front_j;
 				const bool any_graze = __ballot(walk && graze) != 0ull;
@@ -429,9 +434,9 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				if (from_root) { best = RTMI_INFINITY; pos = RTMI_MISS; sp = 0; cur = S.root_ref; }
 				else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
 				if (__ballot(cur != kSentinel) != 0ull) {
-					FF_COUNT(5, 1);
+					FF_COUNT(5, 1); FF_COUNT(72, any_graze ? 1 : 0); FF_COUNT_LANES(73, walk && graze && cur != kSentinel); FF_COUNT_LANES(78, cur != kSentinel);
 					const RayF rf = make_rayf(S, org.x, org.y, org.z, dir.x, dir.y, dir.z);
-					trace_from(S, rf, org.x, org.y, org.z, dir.x, dir.y, dir.z, best, pos, cur, sp, stack);
+					trace_from(S, rf, org.x, org.y, org.z, dir.x, dir.y, dir.z, best, pos, cur, sp, stack, any_graze ? 1u : 0u);
 				}
 				if (shoot && pos != RTMI_MISS) {
 					// hit.point = o + (d·((v1 − o)·n)) / (n·d) with the HIT triangle's first vertex and normal (object.cpp:23),
@@ -646,7 +651,8 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	W.verts = h_verts.data();
 	W.normals = h_normals.data();
 	// "behind its patch's plane" flags: only when the p formula of ANY triangle that might win a tie is the true plane
-	// intersection (geometric normals throughout), and while 2·delta/1e-5 stays far below the kernel's cos threshold of 1e-3
+	// intersection (geometric normals throughout), and while delta is small enough for the kernel's cosine threshold
+	// 1.6e6·delta (graze_cos below) to stay at 2e-3 or less
 	W.delta = 9.094947017729282e-13 * (1.0 + (double)s->dev.absmax); // 2^-40·(1 + |coord|max)
 	const char *planes = std::getenv("RTMI_FF_PLANES"); // "0": no plane flags (tests compare both settings)
 	W.flags_on = W.delta <= 1.25e-9 && !(planes && planes[0] == '0') && W.all_normals_geometric();
@@ -681,6 +687,11 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	P->n_groups = n_groups;
 	P->chain_entries = W.chain.size();
 	P->plane_delta = W.flags_on ? W.delta : -1.0;
+	// The cosine below which a ray "grazes" a patch's plane and tests the flagged siblings after all (k_form_factors).  It
+	// scales with delta: 2·delta/graze_cos = 1.25e-6 is the most a flagged triangle can come before the hit on j.  (Fixed at
+	// 1e-3 — the value the largest admissible delta needs — until round 2's last day: in a room of size 10 that made 0.1 % of
+	// the rays graze, and those, running along a wall inside the pad of dozens of its leaves, cost 15-30 % of the kernel.)
+	P->graze_cos = W.flags_on ? 1.6e6 * W.delta : 1e-3;
 	P->ff_ready = true;
 	return 0;
 }
@@ -731,7 +742,7 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		const uint32_t lds = (s->info.max_depth + 1u + pend_cap) * kBlock * (uint32_t)sizeof(int);
 		hipLaunchKernelGGL(k_form_factors, grid, dim3(kBlock), lds, st, s->dev, (const double *)P->d_verts, (const double *)P->d_normals,
 		                   (const double *)P->d_area, P->n, static_cast<const ChainEntry *>(P->d_chain), static_cast<const PatchMeta *>(P->d_meta),
-		                   P->d_dfs, samples, seed, first, count, band, margin, pend_cap, P->n_groups, out, ld);
+		                   P->d_dfs, samples, seed, first, count, band, margin, P->graze_cos, pend_cap, P->n_groups, out, ld);
 		return launch_check(who);
 	};
 	int kernel = 0;

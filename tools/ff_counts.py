@@ -24,7 +24,8 @@ else:
 box = rt.Scene(verts)
 rad = rad = rt.Radiosity(box, normals, None)
 out = (C.c_uint64 * 96)()
-rad.findFormFactor(samples=10, seed=1, row0=(20000 if len(sys.argv) > 3 and sys.argv[3] == 'mixed' else 1000 if len(sys.argv) <= 3 else 0), n_rows=rows)
+row0 = int(os.environ["ROW0"]) if "ROW0" in os.environ else (20000 if len(sys.argv) > 3 and sys.argv[3] == 'mixed' else 1000 if len(sys.argv) <= 3 else 0)
+rad.findFormFactor(samples=10, seed=1, row0=row0, n_rows=rows)
 torch.cuda.synchronize()
 rt.lib.rtmi_debug_ff_counts(out)
 c = list(out)
@@ -38,3 +39,5 @@ print("per pair-row (wave): beam-walk visits %.2f, path-i levels %.2f, shared pa
     c[80] * 10.0 / c[0], c[81] * 10.0 / c[0], c[82] * 10.0 / c[0], c[10] * 10.0 / c[0]))
 print("sibling boxes hit by a ray, by level (lane count): path i", [int(x) for x in c[16:40]])
 print("                                                   path j", [int(x) for x in c[48:72]])
+print("trace_from calls with a grazing lane in the wave %d (grazing lanes entering %d, all lanes entering %d); node steps without / with a grazing lane %d / %d, leaf steps %d / %d" % (
+    c[72], c[73], c[78], c[74], c[75], c[76], c[77]))
