@@ -155,6 +155,11 @@ int rtmi_any_hit_dev(rtmi_scene *, const rtmi_ray *d_rays, uint64_t n, uint8_t *
  * counterpart (the reference's BSP, scene.cpp:463-693, is replaced). */
 int rtmi_debug_check_hierarchy(const double *tri_xyz, uint64_t n_tris, uint64_t stats[4]);
 
+/* Test hook, no reference counterpart: n vector divisions (num3[3k..3k+2] / den[k], device pointers) by the library's
+ * shared-reciprocal form (csrc/rtmi_device.hpp: div3, what every `Vec3 / double` of the kernels runs, vec3.h:46) and by the
+ * compiler's three plain IEEE divisions; the tests require the two outputs to be the same bits. */
+int rtmi_debug_div3_dev(const double *d_num3, const double *d_den, uint64_t n, double *d_shared3, double *d_plain3, void *stream);
+
 /* ---- wavefront: secondary rays generated on the device -----------------------------------------------
  * The batch producers between two ray-query calls, so that a frame's hit records never leave HBM:
  * d_rays[k] produced d_hits[k]; d_normals = n_tris × 3 doubles, the reference's triNormal per ORIGINAL triangle

@@ -578,7 +578,40 @@ __device__ __forceinline__ D3 operator+(D3 a, D3 b) { return d3(a.x + b.x, a.y +
 __device__ __forceinline__ D3 operator-(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }     // vec3.h:26
 __device__ __forceinline__ D3 operator*(double s, D3 a) { return d3(s * a.x, s * a.y, s * a.z); }       // vec3.h:34
 __device__ __forceinline__ double dot(D3 a, D3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }   // vec3.h:42
-__device__ __forceinline__ D3 operator/(D3 a, double c) { return d3(a.x / c, a.y / c, a.z / c); }       // vec3.h:46
+// Three IEEE divisions by ONE denominator (vec3.h:46), bit for bit what `a.x / c, a.y / c, a.z / c` give.  The compiler expands a
+// double division into  d' = div_scale(c) ; r = rcp(d') refined by four FMAs ; n' = div_scale(n) ; q = n'·r ; e = n' − d'·q ;
+// div_fmas(e, r, q) ; div_fixup  — twelve instructions, one of them the 17-cycle v_rcp_f64 — and repeats all of it per
+// numerator, because d' may depend on the numerator (the scaling only acts at the ends of the exponent range).  Here the
+// reciprocal and its refinement are computed once when the three scaled denominators are the same bits — always, outside
+// those ends — and the plain divisions run otherwise: the same instructions on the same operands, so the same quotients
+// (tests/test_gpu_parity.py: test_shared_reciprocal_division_is_the_plain_division).  Saves 2 v_rcp_f64 + 10 FMAs per call.
+#ifndef RTMI_PLAIN_DIV3
+__device__ __forceinline__ D3 div3(D3 a, double c) {
+	bool s0, s1, s2, unused;
+	const double dx = __builtin_amdgcn_div_scale(a.x, c, false, &unused);
+	const double dy = __builtin_amdgcn_div_scale(a.y, c, false, &unused);
+	const double dz = __builtin_amdgcn_div_scale(a.z, c, false, &unused);
+	if (__double_as_longlong(dx) == __double_as_longlong(dy) && __double_as_longlong(dx) == __double_as_longlong(dz)) {
+		double r = __builtin_amdgcn_rcp(dx);
+		const double f0 = __builtin_fma(-dx, r, 1.0);
+		r = __builtin_fma(r, f0, r);
+		const double f2 = __builtin_fma(-dx, r, 1.0);
+		r = __builtin_fma(r, f2, r);
+		const double nx = __builtin_amdgcn_div_scale(a.x, c, true, &s0);
+		const double ny = __builtin_amdgcn_div_scale(a.y, c, true, &s1);
+		const double nz = __builtin_amdgcn_div_scale(a.z, c, true, &s2);
+		const double qx = nx * r, qy = ny * r, qz = nz * r;
+		const double ex = __builtin_fma(-dx, qx, nx), ey = __builtin_fma(-dx, qy, ny), ez = __builtin_fma(-dx, qz, nz);
+		return d3(__builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(ex, r, qx, s0), c, a.x),
+		          __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(ey, r, qy, s1), c, a.y),
+		          __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(ez, r, qz, s2), c, a.z));
+	}
+	return d3(a.x / c, a.y / c, a.z / c);
+}
+#else
+__device__ __forceinline__ D3 div3(D3 a, double c) { return d3(a.x / c, a.y / c, a.z / c); }
+#endif
+__device__ __forceinline__ D3 operator/(D3 a, double c) { return div3(a, c); }                            // vec3.h:46
 __device__ __forceinline__ double len2(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }              // vec3.h:14
 __device__ __forceinline__ D3 unit(D3 a) {                                                              // vec3.h:98
 	const double d = len2(a);

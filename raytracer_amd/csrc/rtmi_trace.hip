@@ -859,6 +859,26 @@ static int debug_check_hierarchy(const double *tri_xyz, uint64_t n_tris, uint64_
 	return 0;
 }
 
+// test hook: the shared-reciprocal vector division of rtmi_device.hpp beside the compiler's plain divisions
+__global__ void k_debug_div3(const double *__restrict__ num3, const double *__restrict__ den, uint64_t n, double *__restrict__ shared3,
+                             double *__restrict__ plain3) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	const D3 a = d3(num3[3 * k], num3[3 * k + 1], num3[3 * k + 2]);
+	const double c = den[k];
+	const D3 q = div3(a, c);
+	shared3[3 * k] = q.x; shared3[3 * k + 1] = q.y; shared3[3 * k + 2] = q.z;
+	plain3[3 * k] = a.x / c; plain3[3 * k + 1] = a.y / c; plain3[3 * k + 2] = a.z / c;
+}
+int rtmi_debug_div3_dev(const double *d_num3, const double *d_den, uint64_t n, double *d_shared3, double *d_plain3, void *stream) {
+	const char *who = "rtmi_debug_div3_dev";
+	if (n == 0) return 0;
+	if (!d_num3 || !d_den || !d_shared3 || !d_plain3) return fail(std::string(who) + ": NULL argument");
+	if ((n + 255) / 256 > 0x7fffffffull) return fail(std::string(who) + ": too many elements");
+	hipLaunchKernelGGL(k_debug_div3, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_num3, d_den, n, d_shared3, d_plain3);
+	return launch_check(who);
+}
+
 int rtmi_any_hit_dev(rtmi_scene *s, const rtmi_ray *d_rays, uint64_t n, uint8_t *d_occluded, void *stream) {
 	return trace_dev<true>(s, d_rays, n, nullptr, d_occluded, stream, "rtmi_any_hit_dev");
 }

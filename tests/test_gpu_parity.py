@@ -348,6 +348,48 @@ def test_form_factors_inside_a_graph_capture(rt):
     scene.check()
 
 
+def test_shared_reciprocal_division_is_the_plain_division(rt):
+    """csrc/rtmi_device.hpp div3 (every `Vec3 / double` of the kernels: one reciprocal for three numerators) against the
+    compiler's three IEEE divisions: the same bits on 6 M random operand sets over the whole exponent range — including
+    the ends, where the hardware rescales operands and the shared form must step aside — and on the special values."""
+    import torch
+    rng = np.random.default_rng(11)
+
+    def wide(n):      # random sign, mantissa and exponent (denormals, zeros, infinities and NaN included)
+        bits = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) | (rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63))
+        return bits.view(np.float64)
+
+    n = 1 << 21
+    specials = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
+                         1e-300, 1e300, 3.0, 1.0 / 3.0, 0.1, 2.0 ** -1022, 2.0 ** 1023, 2.0 ** -1074, 1e-5, 0.135])
+    sp = np.array(np.meshgrid(specials, specials, indexing="ij")).reshape(2, -1).T      # all (numerator, denominator) pairs
+    sets = []
+    old_err = np.seterr(all="ignore")
+    # ordinary magnitudes (what the kernels see), wide exponents, near-equal exponents at both ends, the special pairs
+    sets.append((rng.normal(size=(n, 3)) * 10.0 ** rng.integers(-3, 4, size=(n, 1)), rng.normal(size=n) * 10.0 ** rng.integers(-3, 4, size=n)))
+    sets.append((wide(3 * n).reshape(n, 3), wide(n)))
+    big = 2.0 ** rng.integers(960, 1024, size=(n, 1)).astype(np.float64)
+    sets.append((rng.normal(size=(n, 3)) * big * 2.0 ** rng.integers(-60, 1, size=(n, 3)).astype(np.float64), rng.normal(size=n) * 2.0 ** rng.integers(-1074, -900, size=n).astype(np.float64)))
+    sets.append((rng.normal(size=(n, 3)) * 2.0 ** rng.integers(-1074, -900, size=(n, 3)).astype(np.float64), rng.normal(size=n) * big[:, 0]))
+    sets.append((np.stack([sp[:, 0], np.roll(sp[:, 0], 1), np.roll(sp[:, 0], 7)], 1), sp[:, 1]))
+    np.seterr(**old_err)
+    with np.errstate(all="ignore"):
+        for num, den in sets:
+            d_num = torch.from_numpy(np.ascontiguousarray(num, dtype=np.float64)).cuda()
+            d_den = torch.from_numpy(np.ascontiguousarray(den, dtype=np.float64)).cuda()
+            a = torch.zeros_like(d_num)
+            b = torch.zeros_like(d_num)
+            rc = rt.lib.rtmi_debug_div3_dev(d_num.data_ptr(), d_den.data_ptr(), len(den), a.data_ptr(), b.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rt.lib.rtmi_last_error().decode()
+            torch.cuda.synchronize()
+            ga, gb = a.cpu().numpy(), b.cpu().numpy()
+            want = num / den[:, None]                                    # the host's IEEE division
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(gb), nan) and np.array_equal(np.isnan(ga), nan)
+            assert np.array_equal(gb.view(np.uint64)[~nan], want.view(np.uint64)[~nan])      # the compiler's division is IEEE
+            assert np.array_equal(ga.view(np.uint64)[~nan], want.view(np.uint64)[~nan])      # ... and so is the shared form
+
+
 def test_patches_must_be_the_scenes_triangles(rt):
     from raytracer_amd import workloads
     v = workloads.soup(50, seed=2, edge=0.3)
