@@ -246,7 +246,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
                                                            const double *__restrict__ p_area, uint32_t p_n, const ChainEntry *__restrict__ t_chain,
                                                            const PatchMeta *__restrict__ t_meta, const uint32_t *__restrict__ t_dfs,
                                                            uint32_t samples, uint64_t seed, uint32_t row0, uint32_t n_rows, uint32_t band_rows,
-                                                           float margin, double graze_cos, uint32_t pend_cap, uint32_t n_groups, float *__restrict__ F, uint64_t ld) {
+                                                           float margin, double graze_cos_i, double graze_cos_j, uint32_t pend_cap, uint32_t n_groups, float *__restrict__ F, uint64_t ld) {
 	struct { const double *verts, *normals, *area; uint32_t n; } P = {p_verts, p_normals, p_area, p_n};
 	struct { const ChainEntry *chain; const PatchMeta *meta; const uint32_t *dfs; } T = {t_chain, t_meta, t_dfs};
 	extern __shared__ int stack_all[];
@@ -293,10 +293,10 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 			// boxes' centres.  `margin` covers the 1e-5, the per-ray pad of the exact test and all fp32 roundings.
 			// mask_i / mask_j: bit L = the sibling at level L of path i / path j may be met by a ray of this pair.
 			// *_front: without the siblings that lie wholly behind (or in) the patch's own plane — flagged on the host, in
-			// double, from exact bounds (build_ff_tables: nothing of the sibling is more than delta above the plane).  With
-			// graze_cos = 1.6e6·delta (host; 1.6e-5 in a room of size 10): a ray that leaves patch i with cos > graze_cos is
-			// 1e-5·cos > 16·delta above that plane at its origin and rises, so it meets such triangles only at t < 0; one that
-			// arrives on j with cos > graze_cos is delta above j's plane no earlier than delta/cos < 6.3e-7 before its hit on j,
+			// double, from exact bounds (build_ff_tables: nothing of the sibling is more than delta above the plane).  A ray
+			// that leaves patch i with cos > graze_cos_i = 4e5·delta (host; 4e-6 in a room of size 10) is 1e-5·cos > 4·delta
+			// above that plane at its origin and rises, so it meets such triangles only at t < 0; one that arrives on j with
+			// cos > graze_cos_j = 1.6e6·delta is delta above j's plane no earlier than delta/cos < 6.3e-7 before its hit on j,
 			// so it meets them no earlier than that — where every hit gives the verdict the hit on j gives (|p − xj| < 1e-5
 			// with a factor 16 to spare for the roundings of t and p, which are of relative size 1e-15/cos).
 			uint32_t mask_i = 0u, mask_j = 0u, front_i = 0u, front_j = 0u;
@@ -403,11 +403,13 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				// Triangle i lies 1e-5 BEHIND the origin along the ray (t = −1e-5 up to rounding of relative size 1e-15/c1): it
 				// cannot be hit unless the ray all but grazes it — then it is tested like any other, and so is everything
 				// behind the two planes.
-				const bool graze = !(c1 > graze_cos && c2 > graze_cos);
-				if (walk && (graze || S.absmax > 1e4f)) push((int)~(mi.leafpos << 3));
-				const uint32_t s_i = graze ? mask_i : front_i, s_j = graze ? mask_j : front_j;
-				const bool any_graze = __ballot(walk && graze) != 0ull;
-				const uint32_t um_i = any_graze ? um_i_all : um_i_front, um_j = any_graze ? um_j_all : um_j_front;
+				// (each end on its own: what lies behind i's plane matters to a ray that grazes i, whatever it does at j)
+				const bool graze_i = !(c1 > graze_cos_i), graze_j = !(c2 > graze_cos_j);
+				if (walk && (graze_i || S.absmax > 1e4f)) push((int)~(mi.leafpos << 3));
+				const uint32_t s_i = graze_i ? mask_i : front_i, s_j = graze_j ? mask_j : front_j;
+				const bool any_graze_i = __ballot(walk && graze_i) != 0ull, any_graze_j = __ballot(walk && graze_j) != 0ull;
+				const bool any_graze = any_graze_i || any_graze_j; (void)any_graze;
+				const uint32_t um_i = any_graze_i ? um_i_all : um_i_front, um_j = any_graze_j ? um_j_all : um_j_front;
 				const uint32_t own_j = s_j & ~low;
 				// the siblings the beam met, against THIS ray (exact slab test, bounded by the hit on j)
 				for (uint32_t m = um_i; m; m &= m - 1u) { // wave-uniform
@@ -434,7 +436,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				if (from_root) { best = RTMI_INFINITY; pos = RTMI_MISS; sp = 0; cur = S.root_ref; }
 				else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
 				if (__ballot(cur != kSentinel) != 0ull) {
-					FF_COUNT(5, 1); FF_COUNT(72, any_graze ? 1 : 0); FF_COUNT_LANES(73, walk && graze && cur != kSentinel); FF_COUNT_LANES(78, cur != kSentinel);
+					FF_COUNT(5, 1); FF_COUNT(72, any_graze ? 1 : 0); FF_COUNT_LANES(73, walk && (graze_i || graze_j) && cur != kSentinel); FF_COUNT_LANES(78, cur != kSentinel);
 					const RayF rf = make_rayf(S, org.x, org.y, org.z, dir.x, dir.y, dir.z);
 					trace_from(S, rf, org.x, org.y, org.z, dir.x, dir.y, dir.z, best, pos, cur, sp, stack, any_graze ? 1u : 0u);
 				}
@@ -687,11 +689,14 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	P->n_groups = n_groups;
 	P->chain_entries = W.chain.size();
 	P->plane_delta = W.flags_on ? W.delta : -1.0;
-	// The cosine below which a ray "grazes" a patch's plane and tests the flagged siblings after all (k_form_factors).  It
-	// scales with delta: 2·delta/graze_cos = 1.25e-6 is the most a flagged triangle can come before the hit on j.  (Fixed at
+	// The cosines below which a ray "grazes" a patch's plane and tests the flagged siblings after all (k_form_factors).  They
+	// scale with delta: 2·delta/graze_cos_j = 1.25e-6 is the most a flagged triangle can come before the hit on j.  (Fixed at
 	// 1e-3 — the value the largest admissible delta needs — until round 2's last day: in a room of size 10 that made 0.1 % of
 	// the rays graze, and those, running along a wall inside the pad of dozens of its leaves, cost 15-30 % of the kernel.)
-	P->graze_cos = W.flags_on ? 1.6e6 * W.delta : 1e-3;
+	P->graze_cos_j = W.flags_on ? 1.6e6 * W.delta : 1e-3;
+	// At the leaving end the ray only has to START above the flagged siblings: 1e-5·cos > 4·delta (the roundings of the
+	// origin and of the host's flags are 1e-4 of delta).
+	P->graze_cos_i = W.flags_on ? 4.0e5 * W.delta : 1e-3;
 	P->ff_ready = true;
 	return 0;
 }
@@ -742,7 +747,7 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		const uint32_t lds = (s->info.max_depth + 1u + pend_cap) * kBlock * (uint32_t)sizeof(int);
 		hipLaunchKernelGGL(k_form_factors, grid, dim3(kBlock), lds, st, s->dev, (const double *)P->d_verts, (const double *)P->d_normals,
 		                   (const double *)P->d_area, P->n, static_cast<const ChainEntry *>(P->d_chain), static_cast<const PatchMeta *>(P->d_meta),
-		                   P->d_dfs, samples, seed, first, count, band, margin, P->graze_cos, pend_cap, P->n_groups, out, ld);
+		                   P->d_dfs, samples, seed, first, count, band, margin, P->graze_cos_i, P->graze_cos_j, pend_cap, P->n_groups, out, ld);
 		return launch_check(who);
 	};
 	int kernel = 0;

@@ -25,7 +25,7 @@ struct rtmi_patches {
 	uint32_t n_groups = 0;     // 64-patch groups of d_dfs
 	uint64_t chain_entries = 0;
 	double plane_delta = -1.0; // tolerance of the "behind the patch's plane" tests, < 0: the tests are off
-	double graze_cos = 1e-3;   // rays with a smaller cosine at either end test the flagged siblings too (rtmi_formfactor.hip)
+	double graze_cos_i = 1e-3, graze_cos_j = 1e-3; // rays leaving i / arriving on j with a smaller cosine test the flagged siblings of that path too (rtmi_formfactor.hip)
 };
 
 namespace rtmi {
