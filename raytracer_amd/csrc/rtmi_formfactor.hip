@@ -389,13 +389,6 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 					if (t > 0.0) { best = t; pos = mj.leafpos; walk = true; }
 					else from_root = true;
 				}
-				const float tb0 = f32_above(best);
-				RayS rs;
-				{
-					const float fx = (float)org.x, fy = (float)org.y, fz = (float)org.z;
-					const float pad = 3.814697265625e-06f * (S.absmax + fmaxf(fabsf(fx), fmaxf(fabsf(fy), fabsf(fz)))) + 1e-30f; // as make_rayf
-					rs = make_rays(fx, fy, fz, (float)dir.x, (float)dir.y, (float)dir.z, pad, pad, pad);
-				}
 				auto push = [&](int ref) {
 					if ((uint32_t)sp < pend_cap) { stack[sp * kBlock] = ref; ++sp; }
 					else from_root = true;
@@ -411,7 +404,16 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				const bool any_graze = any_graze_i || any_graze_j; (void)any_graze;
 				const uint32_t um_i = any_graze_i ? um_i_all : um_i_front, um_j = any_graze_j ? um_j_all : um_j_front;
 				const uint32_t own_j = s_j & ~low;
-				// the siblings the beam met, against THIS ray (exact slab test, bounded by the hit on j)
+				// the siblings the beam met, against THIS ray (exact slab test, bounded by the hit on j) — two waves in three have
+				// none for a sample, and skip the fp32 ray with them
+				if ((um_i | um_j) != 0u || __ballot(walk && own_j != 0u) != 0ull) {
+				const float tb0 = f32_above(best);
+				RayS rs;
+				{
+					const float fx = (float)org.x, fy = (float)org.y, fz = (float)org.z;
+					const float pad = 3.814697265625e-06f * (S.absmax + fmaxf(fabsf(fx), fmaxf(fabsf(fy), fabsf(fz)))) + 1e-30f; // as make_rayf
+					rs = make_rays(fx, fy, fz, (float)dir.x, (float)dir.y, (float)dir.z, pad, pad, pad);
+				}
 				for (uint32_t m = um_i; m; m &= m - 1u) { // wave-uniform
 					FF_COUNT(1, 1);
 					const uint32_t L = (uint32_t)__builtin_ctz(m);
@@ -431,6 +433,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 						const float4 a = *reinterpret_cast<const float4 *>(chain_j + L), b = *(reinterpret_cast<const float4 *>(chain_j + L) + 1);
 						if (slab_box(a, b, rs, tb0)) { push(__float_as_int(a.w)); FF_COUNT(48 + L, 1); }
 					}
+				}
 				}
 				FF_COUNT_LANES(8, from_root); FF_COUNT(4, __popcll(__ballot(sp > 0))); FF_COUNT(14, __popcll(__ballot(sp > 1))); FF_COUNT(15, __popcll(__ballot(sp > 2)));
 				if (from_root) { best = RTMI_INFINITY; pos = RTMI_MISS; sp = 0; cur = S.root_ref; }
