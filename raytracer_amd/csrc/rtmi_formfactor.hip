@@ -446,10 +446,15 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				if (shoot && pos != RTMI_MISS) {
 					// hit.point = o + (d·((v1 − o)·n)) / (n·d) with the HIT triangle's first vertex and normal (object.cpp:23),
 					// visible ⇔ |hit.point − xj| < 1e-5 ∧ d·n_j < 0 (radiosity.cpp:249-252; the latter is c2 > 0)
-					const GTri &Th = S.tris[pos];
-					const double *np = P.normals + 3 * (size_t)Th.orig;
-					const D3 n = d3(np[0], np[1], np[2]);
-					const D3 v1 = d3(Th.v0[0], Th.v0[1], Th.v0[2]);
+					// (nearly always the hit IS triangle j: its first vertex and normal are at hand — the same bits as the two
+					// dependent loads through tris[pos] would fetch, which only a ray stopped by something else needs)
+					D3 n = nj, v1 = d3(ejp[0], ejp[1], ejp[2]);
+					if (pos != mj.leafpos) {
+						const GTri &Th = S.tris[pos];
+						const double *np = P.normals + 3 * (size_t)Th.orig;
+						n = d3(np[0], np[1], np[2]);
+						v1 = d3(Th.v0[0], Th.v0[1], Th.v0[2]);
+					}
 					const D3 p = org + (dot(v1 - org, n) * dir) / dot(n, dir);
 					if (len2(p - xj) < kEpsilonSquaredExact) { // sqrt(...) < 1e-5 exactly (rtmi_rad_device.hpp)
 						const double cosFactor = c1 * c2;
