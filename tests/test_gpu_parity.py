@@ -281,6 +281,43 @@ def test_form_factor_path_walk_equals_root_traversal_and_oracle(rt, oracle, monk
         assert np.array_equal(part, F_path[61:136])
 
 
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (0.002, 0.0), (130.0, 0.0), (1.0, 900.0), (0.05, -37.5)])
+def test_form_factor_grazing_thresholds_follow_the_scene_scale(rt, oracle, monkeypatch, scale, offset):
+    """The cosines below which a ray counts as grazing a patch's plane (and tests what lies in or behind that plane after
+    all) scale with the tolerance of the host's plane flags, 2^-40·(1 + |coord|max) — rtmi_formfactor.hip.  A long low
+    corridor (8 x 1 x 0.25, finely meshed floor and ceiling: thousands of rays per row leave or arrive at less than a
+    thousandth of a radian) at several sizes and far from the origin: the path walk with the flags on, with the flags
+    off, and the root traversal give the same bits; rows equal the oracle's."""
+    from raytracer_amd import workloads
+    vb, nb, _ = workloads.closed_box(12)
+    squash = np.array([0.8, 0.1, 0.025] * 3)                    # the 10-box becomes 8 x 1 x 0.25
+    verts = vb * squash * scale + offset
+    normals = nb.copy()
+    n = len(verts)
+    scene = rt.Scene(verts)
+
+    def build(kernel, planes):
+        monkeypatch.setenv("RTMI_FF_KERNEL", kernel)
+        monkeypatch.setenv("RTMI_FF_PLANES", planes)
+        rad = rt.Radiosity(scene, normals, None)                 # (the flags are fixed when a patch set's tables are built)
+        F = rad.findFormFactor(samples=10, seed=21).cpu().numpy()[:, :n]
+        rad.close()
+        return F
+
+    F_on = build("path", "1")
+    F_off = build("path", "0")
+    F_flat = build("flat", "1")
+    monkeypatch.delenv("RTMI_FF_PLANES", raising=False)
+    monkeypatch.setenv("RTMI_FF_KERNEL", "path")
+    assert np.array_equal(F_on.view(np.uint32), F_flat.view(np.uint32))
+    assert np.array_equal(F_off.view(np.uint32), F_flat.view(np.uint32))
+    for r in (0, n // 2 + 3, n - 1):
+        want = oracle.form_factors(verts, normals, 10, 21, row0=r, n_rows=1)[0].astype(np.float32)
+        assert np.array_equal(F_on[r], want)
+    assert (F_on > 0).mean() > 0.3
+    scene.check()
+
+
 @pytest.mark.parametrize("stem,row0", [("real_full_room", 7000), ("real_buddha", 1500)])
 def test_form_factors_on_the_references_meshes(rt, oracle, monkeypatch, stem, row0):
     """The path walk on real meshes (the reference's full_room.obj: furniture inside a room, 78 zero-area faces, vertex
