@@ -293,12 +293,13 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 			// boxes' centres.  `margin` covers the 1e-5, the per-ray pad of the exact test and all fp32 roundings.
 			// mask_i / mask_j: bit L = the sibling at level L of path i / path j may be met by a ray of this pair.
 			// *_front: without the siblings that lie wholly behind (or in) the patch's own plane — flagged on the host, in
-			// double, from exact bounds (build_ff_tables: nothing of the sibling is more than delta above the plane).  A ray
-			// that leaves patch i with cos > graze_cos_i = 4e5·delta (host; 4e-6 in a room of size 10) is 1e-5·cos > 4·delta
-			// above that plane at its origin and rises, so it meets such triangles only at t < 0; one that arrives on j with
-			// cos > graze_cos_j = 1.6e6·delta is delta above j's plane no earlier than delta/cos < 6.3e-7 before its hit on j,
+			// double, from exact bounds (build_ff_tables: nothing of the sibling is more than delta above the plane through the
+			// patch's first vertex, heights taken along the caller's normal; the patch itself lies within delta/4 of it).  A ray
+			// that leaves patch i with cos > graze_cos = 4e5·delta (host; 4e-6 in a room of size 10) is 1e-5·cos − delta/4 >
+			// 3·delta above that plane at its origin and rises, so it meets such triangles only at t < 0; one that arrives on j
+			// with cos > graze_cos is delta above j's plane no earlier than (delta + delta/4)/cos < 3.2e-6 before its hit on j,
 			// so it meets them no earlier than that — where every hit gives the verdict the hit on j gives (|p − xj| < 1e-5
-			// with a factor 16 to spare for the roundings of t and p, which are of relative size 1e-15/cos).
+			// with a factor 3 to spare; the roundings of t and p are of relative size 1e-15/cos, a thousandth of that).
 			uint32_t mask_i = 0u, mask_j = 0u, front_i = 0u, front_j = 0u;
 			const uint32_t xij = mi.path ^ mj.path, xi0 = mi.path ^ m0.path;
 			const uint32_t lca = (pair && xij) ? (uint32_t)(__ffs((int)xij) - 1) : 0u;     // first level where the paths part
@@ -614,13 +615,17 @@ struct TableWalk {
 		sib.pop_back();
 		sib_box.pop_back();
 	}
-	// the caller's normal of patch id equals ± Unit((v2 − v1) ^ (v3 − v1)) to 1e-9 per component
+	// the caller's normal of patch id equals ± Unit((v2 − v1) ^ (v3 − v1)) to 1e-9 per component, AND the patch lies in the
+	// plane through its first vertex perpendicular to that normal to delta/4 (its other two vertices do, hence all of it):
+	// heights along the CALLER's normal are what the flags below and the kernel's cosines measure, so this is the bound on
+	// how far a point of the patch itself — a ray's origin on i, its hit on j — can sit off the plane the flags refer to
 	bool normal_is_geometric(uint32_t id) const {
 		const double *v = verts + 9 * (size_t)id, *nr = normals + 3 * (size_t)id;
 		const double ax = v[3] - v[0], ay = v[4] - v[1], az = v[5] - v[2], bx = v[6] - v[0], by = v[7] - v[1], bz = v[8] - v[2];
 		double g[3] = {ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx};
 		const double len = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
 		if (!(len > 0.0)) return false;
+		if (std::fabs(nr[0] * ax + nr[1] * ay + nr[2] * az) > 0.25 * delta || std::fabs(nr[0] * bx + nr[1] * by + nr[2] * bz) > 0.25 * delta) return false;
 		double dp = 0.0, dm = 0.0;
 		for (int a = 0; a < 3; ++a) {
 			dp = std::max(dp, std::fabs(nr[a] - g[a] / len));
@@ -662,7 +667,7 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	W.normals = h_normals.data();
 	// "behind its patch's plane" flags: only when the p formula of ANY triangle that might win a tie is the true plane
 	// intersection (geometric normals throughout), and while delta is small enough for the kernel's cosine threshold
-	// 1.6e6·delta (graze_cos below) to stay at 2e-3 or less
+	// 4e5·delta (graze_cos below) to stay at 5e-4 or less
 	W.delta = 9.094947017729282e-13 * (1.0 + (double)s->dev.absmax); // 2^-40·(1 + |coord|max)
 	const char *planes = std::getenv("RTMI_FF_PLANES"); // "0": no plane flags (tests compare both settings)
 	W.flags_on = W.delta <= 1.25e-9 && !(planes && planes[0] == '0') && W.all_normals_geometric();
@@ -698,10 +703,10 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	P->chain_entries = W.chain.size();
 	P->plane_delta = W.flags_on ? W.delta : -1.0;
 	// The cosines below which a ray "grazes" a patch's plane and tests the flagged siblings after all (k_form_factors).  They
-	// scale with delta: 2·delta/graze_cos_j = 1.25e-6 is the most a flagged triangle can come before the hit on j.  (Fixed at
+	// scale with delta: 1.25·delta/graze_cos_j = 3.1e-6 is the most a flagged triangle can come before the hit on j.  (Fixed at
 	// 1e-3 — the value the largest admissible delta needs — until round 2's last day: in a room of size 10 that made 0.1 % of
 	// the rays graze, and those, running along a wall inside the pad of dozens of its leaves, cost 15-30 % of the kernel.)
-	P->graze_cos_j = W.flags_on ? 1.6e6 * W.delta : 1e-3;
+	P->graze_cos_j = W.flags_on ? 4.0e5 * W.delta : 1e-3;
 	// At the leaving end the ray only has to START above the flagged siblings: 1e-5·cos > 4·delta (the roundings of the
 	// origin and of the host's flags are 1e-4 of delta).
 	P->graze_cos_i = W.flags_on ? 4.0e5 * W.delta : 1e-3;
