@@ -330,8 +330,12 @@ int rtmi_visible_points(rtmi_patches *, uint64_t m, const int32_t *ej, const dou
  * waits for the measurement; RTMI_FF_KERNEL=path|flat in the environment forces one.  A call whose stream is being captured
  * into a graph measures nothing (it takes what an earlier call settled, else the path kernel); the per-patch-set tables of the
  * path kernel are built (hipMalloc, copies) by the FIRST call that uses it, so make one call outside the capture first.
- * rtmi_debug_form_factor_kernel: 0 = not measured yet, 1 = paths, 2 = root (diagnostic; no reference counterpart). */
+ * rtmi_debug_form_factor_kernel: 0 = not measured yet, 1 = paths, 2 = root (diagnostic; no reference counterpart).
+ * rtmi_debug_form_factor_planes: 1 = the path kernel's tables carry the "sibling lies behind this patch's plane" flags, 0 = they
+ * do not (caller normals that are not the triangles' geometric ones, |coordinates| beyond ~1 400, RTMI_FF_PLANES=0), -1 = the
+ * tables are not built yet (diagnostic; no reference counterpart). */
 int rtmi_debug_form_factor_kernel(rtmi_patches *);
+int rtmi_debug_form_factor_planes(rtmi_patches *);
 int rtmi_form_factors_dev(rtmi_patches *, const double *light_center, uint32_t samples, uint32_t light_samples,
                           uint64_t seed, uint32_t flags, uint32_t row0, uint32_t n_rows, float *d_F, uint64_t ld,
                           void *stream);

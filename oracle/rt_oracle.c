@@ -336,9 +336,10 @@ uint64_t rto_hash(uint64_t seed, uint32_t a, uint32_t b, uint32_t k, uint32_t wh
 
 void rto_sample_point(const double *e, uint64_t seed, uint32_t a, uint32_t b, uint32_t k, uint32_t which,
                       double p[3]) {
+	/* one hash per point: upper 32 bits -> u, lower 32 bits -> v, each k·2^-32 (exact in double) */
 	uint64_t h = rto_hash(seed, a, b, k, which);
-	double u = (double)(h >> 11) * 0x1.0p-53;
-	double v = (double)(mix64(h) >> 11) * 0x1.0p-53;
+	double u = (double)(uint32_t)(h >> 32) * 0x1.0p-32;
+	double v = (double)(uint32_t)h * 0x1.0p-32;
 	if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
 	double w = 1.0 - u - v;
 	for (int c = 0; c < 3; ++c) p[c] = (w * e[c]) + (u * e[3 + c]) + (v * e[6 + c]); /* util.cpp:113-115 */

@@ -45,11 +45,17 @@ struct __attribute__((aligned(16))) ChainEntry {
 	uint32_t level;
 };
 // Per patch (original id): where its path's siblings start in the chain array, the path itself (bit L = went right at
-// level L), its length, and the position of its triangle in the leaf-ordered array.
+// level L), its length (< 32) with the position of its triangle in the leaf-ordered array (< kMaxFirst = 2^27) in one word,
+// and which of ITS siblings lie wholly behind (or in) ITS plane (bit L = the sibling at level L; build_ff_tables).  The flag
+// belongs to the patch, not to the sibling: two patches of one 64-patch group share their upper siblings but not their planes
+// (a group that straddles an edge of a box, a stair, a curved surface), so each lane reads its own mask.
 struct __attribute__((aligned(16))) PatchMeta {
-	uint32_t chain_off, path, depth, leafpos;
+	uint32_t chain_off, path, depth_leafpos, behind;
 };
-constexpr uint32_t kBehind = 0x100u; // ChainEntry::level: the sibling lies wholly behind (or in) the plane of the path's own patch
+__host__ __device__ __forceinline__ uint32_t meta_depth(const PatchMeta &m) { return m.depth_leafpos >> 27; }
+__host__ __device__ __forceinline__ uint32_t meta_leafpos(const PatchMeta &m) { return m.depth_leafpos & 0x7ffffffu; }
+__host__ __device__ __forceinline__ uint32_t bits_below(uint32_t n) { return n >= 32u ? ~0u : ((1u << n) - 1u); } // levels 0 .. n-1
+__host__ __device__ __forceinline__ uint32_t bits_above(uint32_t n) { return n >= 31u ? 0u : ~((2u << n) - 1u); }  // levels n+1 .. 31
 struct FFTables {
 	const ChainEntry *chain;
 	const PatchMeta *meta;
@@ -236,6 +242,9 @@ RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx
 #ifndef RTMI_FF_WAVES
 #define RTMI_FF_WAVES 4
 #endif
+#ifndef RTMI_FF_SKIP_P
+#define RTMI_FF_SKIP_P 1
+#endif
 // Workgroup = ONE group of 64 patches j (blockIdx.x); its four waves take four consecutive bands of rows i, so the group's
 // per-lane tables are fetched once per workgroup and shared through the L1.  Columns j < n_patches only; the light's row
 // (i == n_patches) is zero (:391-393), the diagonal too (:382).
@@ -246,7 +255,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
                                                            const double *__restrict__ p_area, uint32_t p_n, const ChainEntry *__restrict__ t_chain,
                                                            const PatchMeta *__restrict__ t_meta, const uint32_t *__restrict__ t_dfs,
                                                            uint32_t samples, uint64_t seed, uint32_t row0, uint32_t n_rows, uint32_t band_rows,
-                                                           float margin, double graze_cos_i, double graze_cos_j, uint32_t pend_cap, uint32_t n_groups, float *__restrict__ F, uint64_t ld) {
+                                                           float margin, double graze_cos_i, double graze_cos_j, uint32_t planes_on, uint32_t pend_cap, uint32_t n_groups, float *__restrict__ F, uint64_t ld) {
 	struct { const double *verts, *normals, *area; uint32_t n; } P = {p_verts, p_normals, p_area, p_n};
 	struct { const ChainEntry *chain; const PatchMeta *meta; const uint32_t *dfs; } T = {t_chain, t_meta, t_dfs};
 	extern __shared__ int stack_all[];
@@ -267,6 +276,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 	const uint32_t jj = valid_j ? j : j0;
 	const PatchMeta mj = T.meta[jj];
 	const PatchMeta m0 = T.meta[j0]; // wave-uniform
+	const uint32_t dj = meta_depth(mj), leaf_j = meta_leafpos(mj);
 	const double *ejp = P.verts + 9 * (size_t)jj;
 	const D3 nj = d3(P.normals[3 * (size_t)jj], P.normals[3 * (size_t)jj + 1], P.normals[3 * (size_t)jj + 2]);
 	const double area_j = P.area[jj];
@@ -276,13 +286,19 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 	// The group's paths agree on their first `common` levels: those siblings are the same for every lane (read once per wave
 	// through the scalar cache, chain_0); below, each lane has its own.
 	const uint32_t pdiff = mj.path ^ m0.path;
-	const uint32_t common = wave_min_u32(min(mj.depth, pdiff ? (uint32_t)(__ffs((int)pdiff) - 1) : 32u));
-	const uint32_t max_dj = wave_max_u32(mj.depth);
+	const uint32_t common = wave_min_u32(min(dj, pdiff ? (uint32_t)(__ffs((int)pdiff) - 1) : 32u));
+	const uint32_t low = bits_below(common);
+	// Which levels of path j hold a sibling behind j's plane is j's own affair (PatchMeta::behind).  Of the shared levels, the
+	// wave needs: those SOME lane has to test against its beam (not behind that lane's plane), and those behind SOME lane's
+	// plane (a grazing ray tests them) — both the same for every row.
+	const uint32_t behind_j = mj.behind & bits_below(dj);
+	const uint32_t cand_shared = wave_or_u32(~mj.behind & low), behind_shared = wave_or_u32(mj.behind & low);
 	for (uint32_t r = r_begin; r < r_end; ++r) {
 		const uint32_t i = row0 + r; // wave-uniform
 		double out = 0.0;
 		if (i < P.n) {
 			const PatchMeta mi = T.meta[i];
+			const uint32_t di = meta_depth(mi), leaf_i = meta_leafpos(mi);
 			const double *ei = P.verts + 9 * (size_t)i;
 			const D3 ni = d3(P.normals[3 * (size_t)i], P.normals[3 * (size_t)i + 1], P.normals[3 * (size_t)i + 2]);
 			const ChainEntry *chain_i = T.chain + mi.chain_off;
@@ -292,7 +308,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 			// rounding of patch j's bounds; such a segment stays within max(half extents) of the line between the two
 			// boxes' centres.  `margin` covers the 1e-5, the per-ray pad of the exact test and all fp32 roundings.
 			// mask_i / mask_j: bit L = the sibling at level L of path i / path j may be met by a ray of this pair.
-			// *_front: without the siblings that lie wholly behind (or in) the patch's own plane — flagged on the host, in
+			// front_*: without the siblings that lie wholly behind (or in) the patch's own plane — flagged on the host, in
 			// double, from exact bounds (build_ff_tables: nothing of the sibling is more than delta above the plane through the
 			// patch's first vertex, heights taken along the caller's normal; the patch itself lies within delta/4 of it).  A ray
 			// that leaves patch i with cos > graze_cos = 4e5·delta (host; 4e-6 in a room of size 10) is 1e-5·cos − delta/4 >
@@ -300,10 +316,13 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 			// with cos > graze_cos is delta above j's plane no earlier than (delta + delta/4)/cos < 3.2e-6 before its hit on j,
 			// so it meets them no earlier than that — where every hit gives the verdict the hit on j gives (|p − xj| < 1e-5
 			// with a factor 3 to spare; the roundings of t and p are of relative size 1e-15/cos, a thousandth of that).
-			uint32_t mask_i = 0u, mask_j = 0u, front_i = 0u, front_j = 0u;
+			// A flagged sibling costs NO beam test: it is in mask_* whatever the beam says (only a grazing ray looks at it, and
+			// tests its box itself); the beam is tried on the others alone — in a room, the two or three top levels of a path.
+			uint32_t front_i = 0u, front_j = 0u, um_i_front = 0u, um_j_front = 0u;
 			const uint32_t xij = mi.path ^ mj.path, xi0 = mi.path ^ m0.path;
 			const uint32_t lca = (pair && xij) ? (uint32_t)(__ffs((int)xij) - 1) : 0u;     // first level where the paths part
 			const uint32_t lca0 = xi0 ? (uint32_t)(__ffs((int)xi0) - 1) : 32u;              // ... for the group's first patch (uniform)
+			const uint32_t behind_i = mi.behind & bits_below(di);                            // uniform
 			{
 				float alo[3], ahi[3], blo[3], bhi[3];
 				patch_bounds(ei, alo, ahi);
@@ -318,38 +337,37 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				const float py = fmaxf(ahi[1] - alo[1], bhi[1] - blo[1]) * 0.5f + margin;
 				const float pz = fmaxf(ahi[2] - alo[2], bhi[2] - blo[2]) * 0.5f + margin;
 				const RayS beam = make_rays(cax, cay, caz, cbx - cax, cby - cay, cbz - caz, px, py, pz);
-				for (uint32_t L = 0; L < mi.depth; ++L) { // wave-uniform entries
+				for (uint32_t m = ~mi.behind & bits_below(di); m; m &= m - 1u) { // wave-uniform entries: path i's unflagged levels
 					FF_COUNT(81, 1);
+					const uint32_t L = (uint32_t)__builtin_ctz(m);
 					const float4 a = *reinterpret_cast<const float4 *>(chain_i + L), b = *(reinterpret_cast<const float4 *>(chain_i + L) + 1);
-					if (pair && L != lca && slab_box(a, b, beam, 1.0f)) { // (a sibling behind the plane is not walked: only grazing rays need it)
-						if (__float_as_uint(b.w) & kBehind) mask_i |= 1u << L;
-						else if (beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) { mask_i |= 1u << L; front_i |= 1u << L; }
-					}
+					const bool met = pair && L != lca && slab_box(a, b, beam, 1.0f) && beam_meets_leaf(S, __float_as_int(a.w), beam, stack);
+					if (met) front_i |= 1u << L;
+					if (__ballot(met) != 0ull) um_i_front |= 1u << L;
 				}
 				// path j above the group's common depth: if path i parts from the group there (lca0 < common), every lane's
-				// lca is lca0 and the levels between are the group's shared siblings
-				for (uint32_t L = lca0 + 1u; L < common; ++L) { // wave-uniform entries (empty when lca0 >= common)
+				// lca is lca0 and the levels between are the group's shared siblings (their boxes: one scalar fetch per wave)
+				for (uint32_t m = cand_shared & bits_above(lca0); m; m &= m - 1u) { // wave-uniform entries (none when lca0 >= common)
 					FF_COUNT(82, 1);
+					const uint32_t L = (uint32_t)__builtin_ctz(m);
 					const float4 a = *reinterpret_cast<const float4 *>(chain_0 + L), b = *(reinterpret_cast<const float4 *>(chain_0 + L) + 1);
-					if (pair && slab_box(a, b, beam, 1.0f)) {
-						if (__float_as_uint(b.w) & kBehind) mask_j |= 1u << L;
-						else if (beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) { mask_j |= 1u << L; front_j |= 1u << L; }
-					}
+					const bool met = pair && !((behind_j >> L) & 1u) && slab_box(a, b, beam, 1.0f) && beam_meets_leaf(S, __float_as_int(a.w), beam, stack);
+					if (met) front_j |= 1u << L;
+					if (__ballot(met) != 0ull) um_j_front |= 1u << L;
 				}
-				for (uint32_t L = common; L < max_dj; ++L) { // per-lane entries
+				for (uint32_t m = pair ? (~behind_j & bits_below(dj) & ~low & bits_above(lca)) : 0u; __ballot(m != 0u) != 0ull; m &= m - 1u) { // per-lane entries
 					FF_COUNT(10, 1);
-					if (pair && L > lca && L < mj.depth) {
+					if (m) {
+						const uint32_t L = (uint32_t)__builtin_ctz(m);
 						const float4 a = *reinterpret_cast<const float4 *>(chain_j + L), b = *(reinterpret_cast<const float4 *>(chain_j + L) + 1);
-						if (slab_box(a, b, beam, 1.0f)) {
-							if (__float_as_uint(b.w) & kBehind) mask_j |= 1u << L;
-							else if (beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) { mask_j |= 1u << L; front_j |= 1u << L; }
-						}
+						if (slab_box(a, b, beam, 1.0f) && beam_meets_leaf(S, __float_as_int(a.w), beam, stack)) front_j |= 1u << L;
 					}
 				}
 			}
-			const uint32_t low = common >= 32u ? ~0u : ((1u << common) - 1u);
-			const uint32_t um_i_all = wave_or_u32(mask_i), um_j_all = wave_or_u32(mask_j & low);
-			const uint32_t um_i_front = wave_or_u32(front_i), um_j_front = wave_or_u32(front_j & low);
+			const uint32_t mask_i = pair ? ((behind_i & ~(1u << lca)) | front_i) : 0u;
+			const uint32_t mask_j = pair ? ((behind_j & bits_above(lca)) | front_j) : 0u;
+			// what the WAVE loops over per sample (supersets of the lanes' own bits, which are tested per lane below)
+			const uint32_t um_i_all = behind_i | um_i_front, um_j_all = (behind_shared & bits_above(lca0)) | um_j_front;
 			// ---- the samples of the pair, in the reference's order (:309-330) --------------------------------------
 			const uint64_t h0 = mix64(seed ^ (((uint64_t)i << 32) | jj));
 			double ff = 0.0;
@@ -387,7 +405,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 					for (int a = 0; a < 3; ++a) { Tj.v0[a] = ejp[a]; Tj.e1[a] = ejp[3 + a] - ejp[a]; Tj.e2[a] = ejp[6 + a] - ejp[a]; }
 					double u = 0.0, v = 0.0;
 					const double t = mt_exact(org.x, org.y, org.z, dir.x, dir.y, dir.z, Tj, u, v);
-					if (t > 0.0) { best = t; pos = mj.leafpos; walk = true; }
+					if (t > 0.0) { best = t; pos = leaf_j; walk = true; }
 					else from_root = true;
 				}
 				auto push = [&](int ref) {
@@ -399,7 +417,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				// behind the two planes.
 				// (each end on its own: what lies behind i's plane matters to a ray that grazes i, whatever it does at j)
 				const bool graze_i = !(c1 > graze_cos_i), graze_j = !(c2 > graze_cos_j);
-				if (walk && (graze_i || S.absmax > 1e4f)) push((int)~(mi.leafpos << 3));
+				if (walk && (graze_i || S.absmax > 1e4f)) push((int)~(leaf_i << 3));
 				const uint32_t s_i = graze_i ? mask_i : front_i, s_j = graze_j ? mask_j : front_j;
 				const bool any_graze_i = __ballot(walk && graze_i) != 0ull, any_graze_j = __ballot(walk && graze_j) != 0ull;
 				const bool any_graze = any_graze_i || any_graze_j; (void)any_graze;
@@ -449,15 +467,31 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 					// visible ⇔ |hit.point − xj| < 1e-5 ∧ d·n_j < 0 (radiosity.cpp:249-252; the latter is c2 > 0)
 					// (nearly always the hit IS triangle j: its first vertex and normal are at hand — the same bits as the two
 					// dependent loads through tris[pos] would fetch, which only a ray stopped by something else needs)
-					D3 n = nj, v1 = d3(ejp[0], ejp[1], ejp[2]);
-					if (pos != mj.leafpos) {
-						const GTri &Th = S.tris[pos];
-						const double *np = P.normals + 3 * (size_t)Th.orig;
-						n = d3(np[0], np[1], np[2]);
-						v1 = d3(Th.v0[0], Th.v0[1], Th.v0[2]);
+					// When the hit IS triangle j, the planes are known to be planes (planes_on: every caller normal is the
+					// geometric one and each patch lies within delta/4 of the plane through its first vertex along it — the host's
+					// premise for the flags above) and the ray does not graze j (c2 > graze_cos_j = 4e5·delta), the verdict is known
+					// without p: the ray's line passes within 1e-14·|coord| of xj (roundings of dir and org), xj lies within delta/4
+					// of j's plane, so the line meets that plane within (delta/4 + 1e-14·|coord|)/c2 < 6.3e-7 of xj; the computed p
+					// differs from that point by the roundings of (v1 − o)·n and n·d divided by c2, < 3e-15·|coord|/c2 < 1e-8·|coord|max
+					// /(1 + |coord|max).  Together < 7e-7 against the 1e-5 of the test: visible, as the full evaluation finds
+					// (tests compare the two kernels and the oracle bit for bit; RTMI_FF_SKIP_P=0 builds the full evaluation).
+#if RTMI_FF_SKIP_P
+					bool vis = planes_on != 0u && pos == leaf_j && !graze_j;
+#else
+					bool vis = false;
+#endif
+					if (!vis) {
+						D3 n = nj, v1 = d3(ejp[0], ejp[1], ejp[2]);
+						if (pos != leaf_j) {
+							const GTri &Th = S.tris[pos];
+							const double *np = P.normals + 3 * (size_t)Th.orig;
+							n = d3(np[0], np[1], np[2]);
+							v1 = d3(Th.v0[0], Th.v0[1], Th.v0[2]);
+						}
+						const D3 p = org + (dot(v1 - org, n) * dir) / dot(n, dir);
+						vis = len2(p - xj) < kEpsilonSquaredExact; // sqrt(...) < 1e-5 exactly (rtmi_rad_device.hpp)
 					}
-					const D3 p = org + (dot(v1 - org, n) * dir) / dot(n, dir);
-					if (len2(p - xj) < kEpsilonSquaredExact) { // sqrt(...) < 1e-5 exactly (rtmi_rad_device.hpp)
+					if (vis) {
 						const double cosFactor = c1 * c2;
 						const double delF = cosFactor / ((kPi * dist2) + area_term);
 						if (delF > 0.0) ff += delF;
@@ -570,15 +604,14 @@ struct TableWalk {
 		if (bad) return;
 		if (ref < 0) { // a leaf: ONE triangle (rtmi_scene_create builds leaves of one)
 			const uint32_t code = ~(uint32_t)ref, pos = code >> 3;
-			if ((code & 7u) != 0u || pos >= tris.size()) { bad = true; return; }
+			if ((code & 7u) != 0u || pos >= tris.size() || pos >= kMaxFirst) { bad = true; return; }
 			const uint32_t id = tris[pos].orig;
 			if (id >= meta.size() || seen[id]) { bad = true; return; }
 			seen[id] = 1;
 			meta[id].chain_off = (uint32_t)chain.size();
 			meta[id].path = path;
-			meta[id].depth = depth;
-			meta[id].leafpos = pos;
-			const size_t at = chain.size();
+			meta[id].depth_leafpos = (depth << 27) | pos; // depth < 32 (checked below), pos < kMaxFirst = 2^27 (leaf references)
+			meta[id].behind = 0u;
 			chain.insert(chain.end(), sib.begin(), sib.end());
 			if (flags_on) { // which siblings lie wholly behind (or in) this patch's plane: support of their exact bounds along the normal
 				const double *v1 = verts + 9 * (size_t)id, *nr = normals + 3 * (size_t)id;
@@ -587,7 +620,7 @@ struct TableWalk {
 						const Box3 &b = sib_box[L];
 						double sup = 0.0;
 						for (int a = 0; a < 3; ++a) sup += std::max(nr[a] * (b.lo[a] - v1[a]), nr[a] * (b.hi[a] - v1[a]));
-						if (sup <= delta) chain[at + L].level |= kBehind;
+						if (sup <= delta) meta[id].behind |= 1u << L;
 					}
 			}
 			dfs.push_back(id);
@@ -760,7 +793,7 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		const uint32_t lds = (s->info.max_depth + 1u + pend_cap) * kBlock * (uint32_t)sizeof(int);
 		hipLaunchKernelGGL(k_form_factors, grid, dim3(kBlock), lds, st, s->dev, (const double *)P->d_verts, (const double *)P->d_normals,
 		                   (const double *)P->d_area, P->n, static_cast<const ChainEntry *>(P->d_chain), static_cast<const PatchMeta *>(P->d_meta),
-		                   P->d_dfs, samples, seed, first, count, band, margin, P->graze_cos_i, P->graze_cos_j, pend_cap, P->n_groups, out, ld);
+		                   P->d_dfs, samples, seed, first, count, band, margin, P->graze_cos_i, P->graze_cos_j, P->plane_delta >= 0.0 ? 1u : 0u, pend_cap, P->n_groups, out, ld);
 		return launch_check(who);
 	};
 	int kernel = 0;
@@ -820,6 +853,14 @@ int rtmi_debug_form_factor_kernel(rtmi_patches *P) {
 	if (check_patches(P, "rtmi_debug_form_factor_kernel")) return -1;
 	std::lock_guard<std::mutex> lock(P->ff_mutex);
 	return P->ff_kernel;
+}
+
+// 1 = the path tables of this patch set carry "behind the patch's plane" flags, 0 = they do not (normals that are not the
+// geometric ones, coordinates too large, RTMI_FF_PLANES=0), -1 = no tables yet (or an error)
+int rtmi_debug_form_factor_planes(rtmi_patches *P) {
+	if (check_patches(P, "rtmi_debug_form_factor_planes")) return -1;
+	std::lock_guard<std::mutex> lock(P->ff_mutex);
+	return P->ff_ready ? (P->plane_delta >= 0.0 ? 1 : 0) : -1;
 }
 
 #ifdef RTMI_FF_COUNT

@@ -61,10 +61,15 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 
 // uniform point on patch e for stream (seed, a, b, k, which); barycentric mix as Render2/util.cpp:113-115
 // (h0 = mix64(seed ^ (a << 32 | b)) is the same for every sample of a pair: callers may hoist it)
+// ONE hash per point (round 3; two before): its upper 32 bits give u, its lower 32 bits v, each on a grid of 2^-32 — exact in
+// double, one conversion instruction each instead of the four a 53-bit integer takes, and half the 64-bit multiplies (a
+// 64-bit multiply is four quarter-rate 32-bit ones on gfx950).  The reference draws both from an unseeded mt19937
+// (util.cpp:96-124); the generator is ours; the CPU checker restates it, and
+// tests/test_oracle_golden.py checks the stream's uniformity.
 __device__ __forceinline__ D3 sample_point_h(const double *__restrict__ e, uint64_t h0, uint32_t k, uint32_t which) {
 	const uint64_t h = mix64(h0 ^ (((uint64_t)k << 32) | which));
-	double u = (double)(h >> 11) * 0x1.0p-53;
-	double v = (double)(mix64(h) >> 11) * 0x1.0p-53;
+	double u = (double)(uint32_t)(h >> 32) * 0x1.0p-32;
+	double v = (double)(uint32_t)h * 0x1.0p-32;
 	if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
 	const double w = 1.0 - u - v;
 	return d3((w * e[0]) + (u * e[3]) + (v * e[6]), (w * e[1]) + (u * e[4]) + (v * e[7]),

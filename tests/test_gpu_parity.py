@@ -281,7 +281,71 @@ def test_form_factor_path_walk_equals_root_traversal_and_oracle(rt, oracle, monk
         assert np.array_equal(part, F_path[61:136])
 
 
-@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (0.002, 0.0), (130.0, 0.0), (1.0, 900.0), (0.05, -37.5)])
+def _multi_plane_scenes():
+    """Face-normal geometry (so the host's plane flags are ON) whose 64-patch groups of the form-factor kernel span
+    several planes and have occluders that lie behind one patch's plane and in front of its group mates': a staircase
+    (treads and risers of 8-16 triangles alternate in the leaf order; a lower step hides part of an upper riser from the
+    floor), an L-shaped concave block (one arm hides the other's inner face), a tessellated sphere with a small box
+    beside it — each inside a coarse room."""
+    from raytracer_amd import workloads
+    room, rn, _ = workloads.closed_box(6)
+    out = []
+    steps = [workloads._box((1.0 + 0.7 * s, 3.0, 0.0), (1.7 + 0.7 * s, 7.0, 4.0 - 0.45 * s), 2) for s in range(8)]
+    st = np.concatenate(steps)
+    out.append(("stairs", np.concatenate([room, st]), np.concatenate([rn, workloads.face_normals(st)])))
+    ell = np.concatenate([workloads._box((2.0, 2.0, 0.0), (7.0, 3.5, 3.0), 3), workloads._box((2.0, 3.5, 0.0), (3.5, 7.5, 3.0), 3)])
+    out.append(("L_block", np.concatenate([room, ell]), np.concatenate([rn, workloads.face_normals(ell)])))
+    nt, nph = 14, 28
+    th = np.linspace(0.0, np.pi, nt + 1); ph = np.linspace(0.0, 2.0 * np.pi, nph + 1)
+    c, rad = np.array([5.0, 5.0, 4.0]), 2.2
+    P = lambda a, b: c + rad * np.array([np.sin(th[a]) * np.cos(ph[b]), np.sin(th[a]) * np.sin(ph[b]), np.cos(th[a])])
+    sph = []
+    for a in range(nt):
+        for b in range(nph):
+            p00, p10, p11, p01 = P(a, b), P(a + 1, b), P(a + 1, b + 1), P(a, b + 1)
+            if a > 0: sph.append(np.concatenate([p00, p10, p01]))          # outward: (p10 − p00) x (p01 − p00) points along +r
+            if a < nt - 1: sph.append(np.concatenate([p10, p11, p01]))
+    sph = np.concatenate([np.array(sph), workloads._box((7.4, 4.2, 3.0), (8.2, 5.8, 5.0), 2)])
+    out.append(("sphere", np.concatenate([room, sph]), np.concatenate([rn, workloads.face_normals(sph)])))
+    return out
+
+
+@pytest.mark.parametrize("name", ["stairs", "L_block", "sphere"])
+def test_form_factor_plane_flags_belong_to_the_patch_not_the_group(rt, oracle, monkeypatch, name):
+    """Round 2's path walk read "this sibling lies behind the patch's plane" for the levels a 64-patch group shares from the
+    table of the group's FIRST patch: on geometry whose groups span several planes it skipped occluders in front of a
+    lane's own plane (ADVICE round 2, high).  The flag is per patch now (PatchMeta::behind).  Whole F: path walk with the
+    flags on == root traversal == path walk with the flags off, bit for bit; rows equal the oracle's."""
+    verts, normals = next((v, n) for nm, v, n in _multi_plane_scenes() if nm == name)
+    n = len(verts)
+    scene = rt.Scene(verts)
+
+    def build(kernel, planes):
+        monkeypatch.setenv("RTMI_FF_KERNEL", kernel)
+        monkeypatch.setenv("RTMI_FF_PLANES", planes)
+        rad = rt.Radiosity(scene, normals, None)                 # (the flags are fixed when a patch set's tables are built)
+        F = rad.findFormFactor(samples=10, seed=31).cpu().numpy()[:, :n]
+        on = int(rt.lib.rtmi_debug_form_factor_planes(rad.handle))
+        rad.close()
+        return F, on
+
+    F_on, on = build("path", "1")
+    F_off, off = build("path", "0")
+    F_flat, _ = build("flat", "1")
+    monkeypatch.delenv("RTMI_FF_PLANES", raising=False)
+    monkeypatch.setenv("RTMI_FF_KERNEL", "path")
+    assert on == 1 and off == 0                      # the flags really were on / off
+    bad = np.argwhere(F_on.view(np.uint32) != F_flat.view(np.uint32))
+    assert len(bad) == 0, (len(bad), bad[:8].tolist())
+    assert np.array_equal(F_off.view(np.uint32), F_flat.view(np.uint32))
+    for r in (0, 432 + 5, n - 7):                                # a room patch, two patches of the object inside
+        want = oracle.form_factors(verts, normals, 10, 31, row0=r, n_rows=1)[0].astype(np.float32)
+        assert np.array_equal(F_on[r], want)
+    assert (F_on > 0).mean() > 0.05 and (F_on == 0).mean() > 0.3
+    scene.check()
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (0.002, 0.0), (130.0, 0.0), (1.0, 900.0), (0.05, -37.5), (1.0, 2.0e4), (250.0, 0.0)])
 def test_form_factor_grazing_thresholds_follow_the_scene_scale(rt, oracle, monkeypatch, scale, offset):
     """The cosines below which a ray counts as grazing a patch's plane (and tests what lies in or behind that plane after
     all) scale with the tolerance of the host's plane flags, 2^-40·(1 + |coord|max) — rtmi_formfactor.hip.  A long low

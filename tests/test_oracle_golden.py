@@ -115,6 +115,37 @@ def test_g4_visibility_bits(oracle, stem):
     assert 0 < vis.sum() < len(vis)
 
 
+def test_sample_generator_is_uniform_on_the_triangle(oracle):
+    """The sample generator is ours (the reference's is an unseeded mt19937, util.cpp:96-124): one 64-bit hash per point,
+    upper half -> u, lower half -> v on a 2^-32 grid, folded into the triangle.  On the unit right triangle the points'
+    coordinates ARE (u, v): their density must be flat (chi-square over a 16 x 16 grid's cells inside the triangle), u and v
+    uncorrelated beyond the triangle's own -1/2, and the points of consecutive samples / of the two ends of a pair /
+    of neighbouring pairs independent of each other."""
+    tri = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0])
+    pts = []
+    for i in range(40):
+        for j in range(40):
+            for k in range(10):
+                for which in (0, 1):
+                    pts.append(oracle.sample_point(tri, 1, i, j, k, which)[:2])
+    pts = np.array(pts)
+    n = len(pts)
+    assert np.all(pts >= 0) and np.all(pts.sum(1) <= 1.0) and len(np.unique(pts, axis=0)) == n
+    G = 16
+    cx, cy = np.minimum((pts[:, 0] * G).astype(int), G - 1), np.minimum((pts[:, 1] * G).astype(int), G - 1)
+    counts = np.zeros((G, G)); np.add.at(counts, (cx, cy), 1)
+    inside = np.add.outer(np.arange(G), np.arange(G)) < G - 1          # cells wholly inside the triangle: area 1/G² of 1/2
+    expect = n * 2.0 / (G * G)
+    chi2 = ((counts[inside] - expect) ** 2 / expect).sum()
+    dof = inside.sum()
+    assert abs(chi2 - dof) < 5 * np.sqrt(2 * dof), (chi2, dof)
+    assert abs(np.corrcoef(pts[:, 0], pts[:, 1])[0, 1] + 0.5) < 0.02   # uniform on the triangle: corr(u, v) = −1/2
+    assert abs(pts[:, 0].mean() - 1 / 3) < 0.005 and abs(pts[:, 1].mean() - 1 / 3) < 0.005
+    a = pts.reshape(-1, 10, 2, 2)                                      # [pair, sample, which, coord]
+    for x, y in ((a[:, :-1, 0, 0], a[:, 1:, 0, 0]), (a[:, :, 0, 0], a[:, :, 1, 0]), (a[:-1, :, 0, 1], a[1:, :, 0, 1]), (a[:, :, 0, 1], a[:, :, 1, 0])):
+        assert abs(np.corrcoef(x.ravel(), y.ravel())[0, 1]) < 0.02
+
+
 @pytest.mark.parametrize("stem", ["radiosity_test", "practice_room_enclosed"])
 def test_g4_form_factor_formula_statistics(oracle, stem):
     """findFormFactorTerm samples with an unseeded RNG, so the restated formula (radiosity.cpp:316-332)
