@@ -245,6 +245,9 @@ RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx
 #ifndef RTMI_FF_SKIP_P
 #define RTMI_FF_SKIP_P 1
 #endif
+#ifndef RTMI_FF_SKIP_MT
+#define RTMI_FF_SKIP_MT 1
+#endif
 // Workgroup = ONE group of 64 patches j (blockIdx.x); its four waves take four consecutive bands of rows i, so the group's
 // per-lane tables are fetched once per workgroup and shared through the L1.  Columns j < n_patches only; the light's row
 // (i == n_patches) is zero (:391-393), the diagonal too (:382).
@@ -253,7 +256,7 @@ RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx
 // them, and fetches everything that depends on i alone with scalar loads.)
 RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const double *__restrict__ p_verts, const double *__restrict__ p_normals,
                                                            const double *__restrict__ p_area, uint32_t p_n, const ChainEntry *__restrict__ t_chain,
-                                                           const PatchMeta *__restrict__ t_meta, const uint32_t *__restrict__ t_dfs,
+                                                           const PatchMeta *__restrict__ t_meta, const uint32_t *__restrict__ t_dfs, const float2 *__restrict__ t_gconst,
                                                            uint32_t samples, uint64_t seed, uint32_t row0, uint32_t n_rows, uint32_t band_rows,
                                                            float margin, double graze_cos_i, double graze_cos_j, uint32_t planes_on, uint32_t pend_cap, uint32_t n_groups, float *__restrict__ F, uint64_t ld) {
 	struct { const double *verts, *normals, *area; uint32_t n; } P = {p_verts, p_normals, p_area, p_n};
@@ -293,6 +296,9 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 	// plane (a grazing ray tests them) — both the same for every row.
 	const uint32_t behind_j = mj.behind & bits_below(dj);
 	const uint32_t cand_shared = wave_or_u32(~mj.behind & low), behind_shared = wave_or_u32(mj.behind & low);
+	// the group's two constants of the "certain hit" test below (host: build_ff_tables), wave-uniform
+	const float2 gconst = t_gconst[g];
+	const double sure_margin = (double)gconst.x, sure_cos = (double)gconst.y;
 	for (uint32_t r = r_begin; r < r_end; ++r) {
 		const uint32_t i = row0 + r; // wave-uniform
 		double out = 0.0;
@@ -375,9 +381,10 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				bool shoot = false;
 				D3 xj = d3(0, 0, 0), dir = d3(0, 0, 1), org = d3(0, 0, 0);
 				double c1 = 0.0, c2 = 0.0, dist2 = 0.0;
+				double bmin_j = 0.0;
 				if (pair) {
 					const D3 xi = sample_point_h(ei, h0, k, 0);
-					xj = sample_point_h(ejp, h0, k, 1);
+					xj = sample_point_hb(ejp, h0, k, 1, bmin_j);
 					// Unit(xj − xi) once: the reference evaluates it three times (:235, :317, and Unit(xi − xj) = its exact
 					// negation, :318), and dist2 = (xi−xj)·(xi−xj) is the squared length inside it — same IEEE operations.
 					const D3 vec = xj - xi;
@@ -393,6 +400,38 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				FF_COUNT(0, 1);
 				if (__ballot(shoot) == 0ull) continue;
 				FF_COUNT(13, 1); FF_COUNT_LANES(9, shoot);
+				// Triangle i lies 1e-5 BEHIND the origin along the ray (t = −1e-5 up to rounding of relative size 1e-15/c1): it
+				// cannot be hit unless the ray all but grazes it — then it is tested like any other, and so is everything
+				// behind the two planes.
+				// (each end on its own: what lies behind i's plane matters to a ray that grazes i, whatever it does at j)
+				const bool graze_i = !(c1 > graze_cos_i), graze_j = !(c2 > graze_cos_j);
+#if RTMI_FF_SKIP_MT
+				// ---- the certain hit: nothing to test at all --------------------------------------------------------------
+				// A ray aimed at a point WELL INSIDE triangle j, not grazing either plane, with no sibling of either path left
+				// by the beam for it (s_i = s_j = 0): the exact test on j would accept it, nothing else can stop it, and the
+				// verdict of the hit on j is "visible" (the argument above).  The wave skips the triangle test on j and the
+				// walk when EVERY lane that shoots is such a lane.  "Would accept": the ray passes within 3e-15·|coord|max of
+				// xj = w·v1 + u·v2 + v·v3 (roundings of xj, dir, org), so its exact crossing of j's plane has barycentrics within
+				// 6e-15·|coord|max/(c2·a) of (u, v), a = j's smallest altitude; the test's own u', v' (object.cpp:46-56) differ
+				// from those by the roundings of tvec·pvec, dir·qvec and det = ±2A·c2 — below 2e-15·(|coord|max + edge)·edge/(2A·c2).
+				// The host's per-group constant sure_margin = 1e-12·(1 + |coord|max)·max over the group of (1 + edge)/a is a hundred
+				// times their sum: bmin·c2 > sure_margin puts u', v', u' + v' strictly inside [0, 1]; c2 > sure_cos >= 1.01e-8/(2A)
+				// keeps |det| out of the ±1e-8 window (and is >= graze_cos_j); dist² > 1e-6 keeps t = dist − 1e-5 (error below
+				// 1e-3·sure_margin/c2 < 3.4e-4) positive.  Flat, geometric-normal patches only (planes_on, as for the flags).
+				{
+					const bool sure = planes_on != 0u && !graze_i && c2 > sure_cos && bmin_j * c2 > sure_margin && dist2 > 1e-6 &&
+					                  front_i == 0u && front_j == 0u && !(S.absmax > 1e4f);
+					if (__ballot(shoot && !sure) == 0ull) {
+						FF_COUNT(79, 1);
+						if (shoot) {
+							const double cosFactor = c1 * c2;
+							const double delF = cosFactor / ((kPi * dist2) + area_term);
+							if (delF > 0.0) ff += delF;
+						}
+						continue;
+					}
+				}
+#endif
 				double best = RTMI_INFINITY;
 				uint32_t pos = RTMI_MISS;
 				int cur = kSentinel, sp = 0;
@@ -412,11 +451,6 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 					if ((uint32_t)sp < pend_cap) { stack[sp * kBlock] = ref; ++sp; }
 					else from_root = true;
 				};
-				// Triangle i lies 1e-5 BEHIND the origin along the ray (t = −1e-5 up to rounding of relative size 1e-15/c1): it
-				// cannot be hit unless the ray all but grazes it — then it is tested like any other, and so is everything
-				// behind the two planes.
-				// (each end on its own: what lies behind i's plane matters to a ray that grazes i, whatever it does at j)
-				const bool graze_i = !(c1 > graze_cos_i), graze_j = !(c2 > graze_cos_j);
 				if (walk && (graze_i || S.absmax > 1e4f)) push((int)~(leaf_i << 3));
 				const uint32_t s_i = graze_i ? mask_i : front_i, s_j = graze_j ? mask_j : front_j;
 				const bool any_graze_i = __ballot(walk && graze_i) != 0ull, any_graze_j = __ballot(walk && graze_j) != 0ull;
@@ -718,31 +752,55 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	}
 	W.dfs.resize((size_t)n_groups * 64u, RTMI_MISS);
 	if (W.chain.empty()) W.chain.emplace_back(); // a one-patch scene has no siblings; keep the pointer valid
-	void *d_chain = nullptr, *d_meta = nullptr;
-	uint32_t *d_dfs = nullptr;
-	bool ok = hipMalloc(&d_chain, W.chain.size() * sizeof(ChainEntry)) == hipSuccess && hipMalloc(&d_meta, (size_t)n * sizeof(PatchMeta)) == hipSuccess &&
-	          hipMalloc(&d_dfs, W.dfs.size() * sizeof(uint32_t)) == hipSuccess;
-	ok = ok && hipMemcpy(d_chain, W.chain.data(), W.chain.size() * sizeof(ChainEntry), hipMemcpyHostToDevice) == hipSuccess &&
-	     hipMemcpy(d_meta, W.meta.data(), (size_t)n * sizeof(PatchMeta), hipMemcpyHostToDevice) == hipSuccess &&
-	     hipMemcpy(d_dfs, W.dfs.data(), W.dfs.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
-	if (!ok) {
-		if (d_chain) (void)hipFree(d_chain);
-		if (d_meta) (void)hipFree(d_meta);
-		if (d_dfs) (void)hipFree(d_dfs);
-		return fail(std::string(who) + ": device allocation or upload of the path tables failed");
-	}
-	P->d_chain = d_chain; P->d_meta = d_meta; P->d_dfs = d_dfs;
-	P->n_groups = n_groups;
-	P->chain_entries = W.chain.size();
-	P->plane_delta = W.flags_on ? W.delta : -1.0;
 	// The cosines below which a ray "grazes" a patch's plane and tests the flagged siblings after all (k_form_factors).  They
 	// scale with delta: 1.25·delta/graze_cos_j = 3.1e-6 is the most a flagged triangle can come before the hit on j.  (Fixed at
 	// 1e-3 — the value the largest admissible delta needs — until round 2's last day: in a room of size 10 that made 0.1 % of
 	// the rays graze, and those, running along a wall inside the pad of dozens of its leaves, cost 15-30 % of the kernel.)
-	P->graze_cos_j = W.flags_on ? 4.0e5 * W.delta : 1e-3;
 	// At the leaving end the ray only has to START above the flagged siblings: 1e-5·cos > 4·delta (the roundings of the
 	// origin and of the host's flags are 1e-4 of delta).
-	P->graze_cos_i = W.flags_on ? 4.0e5 * W.delta : 1e-3;
+	const double graze_cos = W.flags_on ? 4.0e5 * W.delta : 1e-3;
+	// Per group of 64 patches, the two constants of the kernel's "certain hit" test (see there): with a = 2A/edge the
+	// smallest altitude and edge the longest edge of a patch,
+	//   sure_margin = 1e-12·(1 + |coord|max)·max (1 + edge)/a     sure_cos = max(graze_cos, max 1.01e-8/(2A))
+	// rounded up to float; a patch without area makes both infinite (its group then always runs the exact test).
+	std::vector<float> gconst(2 * (size_t)n_groups);
+	for (uint32_t g = 0; g < n_groups; ++g) {
+		double margin = 0.0, cosmin = graze_cos;
+		for (uint32_t k = 0; k < 64u; ++k) {
+			const uint32_t id = W.dfs[(size_t)g * 64u + k];
+			if (id == RTMI_MISS) continue;
+			const double *v = h_verts.data() + 9 * (size_t)id;
+			const double a[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, b[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]}, c[3] = {v[6] - v[3], v[7] - v[4], v[8] - v[5]};
+			const double cr[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+			const double twoA = std::sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+			const double edge = std::sqrt(std::max(a[0] * a[0] + a[1] * a[1] + a[2] * a[2], std::max(b[0] * b[0] + b[1] * b[1] + b[2] * b[2], c[0] * c[0] + c[1] * c[1] + c[2] * c[2])));
+			if (!(twoA > 0.0) || !std::isfinite(twoA) || !std::isfinite(edge)) { margin = cosmin = INFINITY; break; }
+			margin = std::max(margin, 1e-12 * (1.0 + (double)s->dev.absmax) * (1.0 + edge) * edge / twoA);
+			cosmin = std::max(cosmin, 1.01e-8 / twoA);
+		}
+		gconst[2 * (size_t)g] = f32_above_h(margin);
+		gconst[2 * (size_t)g + 1] = f32_above_h(cosmin);
+	}
+	void *d_chain = nullptr, *d_meta = nullptr, *d_gconst = nullptr;
+	uint32_t *d_dfs = nullptr;
+	bool ok = hipMalloc(&d_chain, W.chain.size() * sizeof(ChainEntry)) == hipSuccess && hipMalloc(&d_meta, (size_t)n * sizeof(PatchMeta)) == hipSuccess &&
+	          hipMalloc(&d_dfs, W.dfs.size() * sizeof(uint32_t)) == hipSuccess && hipMalloc(&d_gconst, gconst.size() * sizeof(float)) == hipSuccess;
+	ok = ok && hipMemcpy(d_chain, W.chain.data(), W.chain.size() * sizeof(ChainEntry), hipMemcpyHostToDevice) == hipSuccess &&
+	     hipMemcpy(d_meta, W.meta.data(), (size_t)n * sizeof(PatchMeta), hipMemcpyHostToDevice) == hipSuccess &&
+	     hipMemcpy(d_dfs, W.dfs.data(), W.dfs.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess &&
+	     hipMemcpy(d_gconst, gconst.data(), gconst.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+	if (!ok) {
+		if (d_chain) (void)hipFree(d_chain);
+		if (d_meta) (void)hipFree(d_meta);
+		if (d_dfs) (void)hipFree(d_dfs);
+		if (d_gconst) (void)hipFree(d_gconst);
+		return fail(std::string(who) + ": device allocation or upload of the path tables failed");
+	}
+	P->d_chain = d_chain; P->d_meta = d_meta; P->d_dfs = d_dfs; P->d_gconst = d_gconst;
+	P->n_groups = n_groups;
+	P->chain_entries = W.chain.size();
+	P->plane_delta = W.flags_on ? W.delta : -1.0;
+	P->graze_cos_j = P->graze_cos_i = graze_cos;
 	P->ff_ready = true;
 	return 0;
 }
@@ -793,7 +851,7 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		const uint32_t lds = (s->info.max_depth + 1u + pend_cap) * kBlock * (uint32_t)sizeof(int);
 		hipLaunchKernelGGL(k_form_factors, grid, dim3(kBlock), lds, st, s->dev, (const double *)P->d_verts, (const double *)P->d_normals,
 		                   (const double *)P->d_area, P->n, static_cast<const ChainEntry *>(P->d_chain), static_cast<const PatchMeta *>(P->d_meta),
-		                   P->d_dfs, samples, seed, first, count, band, margin, P->graze_cos_i, P->graze_cos_j, P->plane_delta >= 0.0 ? 1u : 0u, pend_cap, P->n_groups, out, ld);
+		                   P->d_dfs, static_cast<const float2 *>(P->d_gconst), samples, seed, first, count, band, margin, P->graze_cos_i, P->graze_cos_j, P->plane_delta >= 0.0 ? 1u : 0u, pend_cap, P->n_groups, out, ld);
 		return launch_check(who);
 	};
 	int kernel = 0;

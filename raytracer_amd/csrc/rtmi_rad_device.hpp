@@ -22,6 +22,7 @@ struct rtmi_patches {
 	void *d_chain = nullptr;   // ChainEntry[]: per patch, the siblings along its root-to-leaf path
 	void *d_meta = nullptr;    // PatchMeta[n]
 	uint32_t *d_dfs = nullptr; // patch ids in depth-first leaf order, padded with RTMI_MISS to a multiple of 64
+	void *d_gconst = nullptr;  // float2[n_groups]: the "certain hit" constants of each group (rtmi_formfactor.hip: sure_margin, sure_cos)
 	uint32_t n_groups = 0;     // 64-patch groups of d_dfs
 	uint64_t chain_entries = 0;
 	double plane_delta = -1.0; // tolerance of the "behind the patch's plane" tests, < 0: the tests are off
@@ -66,14 +67,20 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 // 64-bit multiply is four quarter-rate 32-bit ones on gfx950).  The reference draws both from an unseeded mt19937
 // (util.cpp:96-124); the generator is ours; the CPU checker restates it, and
 // tests/test_oracle_golden.py checks the stream's uniformity.
-__device__ __forceinline__ D3 sample_point_h(const double *__restrict__ e, uint64_t h0, uint32_t k, uint32_t which) {
+// bmin: the smallest of the point's three barycentric weights (exact: u, v and w = 1 − u − v are multiples of 2^-32)
+__device__ __forceinline__ D3 sample_point_hb(const double *__restrict__ e, uint64_t h0, uint32_t k, uint32_t which, double &bmin) {
 	const uint64_t h = mix64(h0 ^ (((uint64_t)k << 32) | which));
 	double u = (double)(uint32_t)(h >> 32) * 0x1.0p-32;
 	double v = (double)(uint32_t)h * 0x1.0p-32;
 	if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
 	const double w = 1.0 - u - v;
+	bmin = fmin(fmin(u, v), w);
 	return d3((w * e[0]) + (u * e[3]) + (v * e[6]), (w * e[1]) + (u * e[4]) + (v * e[7]),
 	          (w * e[2]) + (u * e[5]) + (v * e[8]));
+}
+__device__ __forceinline__ D3 sample_point_h(const double *__restrict__ e, uint64_t h0, uint32_t k, uint32_t which) {
+	double unused;
+	return sample_point_hb(e, h0, k, which, unused);
 }
 __device__ __forceinline__ D3 sample_point(const double *__restrict__ e, uint64_t seed, uint32_t a, uint32_t b,
                                            uint32_t k, uint32_t which) {

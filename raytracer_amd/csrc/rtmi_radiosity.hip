@@ -546,6 +546,7 @@ void rtmi_patches_destroy(rtmi_patches *P) {
 	if (P->d_chain) (void)hipFree(P->d_chain);
 	if (P->d_meta) (void)hipFree(P->d_meta);
 	if (P->d_dfs) (void)hipFree(P->d_dfs);
+	if (P->d_gconst) (void)hipFree(P->d_gconst);
 	delete P;
 }
 

@@ -37,6 +37,7 @@ for n, v in zip(names, c):
     print("%-32s %14d   per ray-iteration %.3f" % (n, v, v / it))
 print("per pair-row (wave): beam-walk visits %.2f, path-i levels %.2f, shared path-j levels %.2f, own path-j levels %.2f" % (
     c[80] * 10.0 / c[0], c[81] * 10.0 / c[0], c[82] * 10.0 / c[0], c[10] * 10.0 / c[0]))
+print("sample iterations taken by the certain-hit path (no triangle test, no walk): %d of %d with a ray" % (c[79], c[13]))
 print("sibling boxes hit by a ray, by level (lane count): path i", [int(x) for x in c[16:40]])
 print("                                                   path j", [int(x) for x in c[48:72]])
 print("trace_from calls with a grazing lane in the wave %d (grazing lanes entering %d, all lanes entering %d); node steps without / with a grazing lane %d / %d, leaf steps %d / %d" % (

@@ -8,8 +8,8 @@
 constexpr int kIters = 4096;
 typedef float f2 __attribute__((ext_vector_type(2)));
 template <int KIND> __global__ void __launch_bounds__(256) k_rate(float *out, float seed) {
-	float a[8]; f2 p[8]; double d[8]; uint32_t u[8];
-	for (int k = 0; k < 8; ++k) { a[k] = seed + k + threadIdx.x; p[k] = f2{a[k], a[k] + 1.f}; d[k] = a[k]; u[k] = (uint32_t)a[k] * 2654435761u; }
+	float a[8]; f2 p[8]; double d[8]; uint32_t u[8]; uint64_t q[8];
+	for (int k = 0; k < 8; ++k) { a[k] = seed + k + threadIdx.x; p[k] = f2{a[k], a[k] + 1.f}; d[k] = a[k]; u[k] = (uint32_t)a[k] * 2654435761u; q[k] = (uint64_t)u[k] * 0x9E3779B97F4A7C15ull; }
 	const float m = seed * 1.0000001f, c = seed * 0.5f;
 	for (int it = 0; it < kIters; ++it) {
 #define OP(K)                                                                                                             \
@@ -26,12 +26,22 @@ template <int KIND> __global__ void __launch_bounds__(256) k_rate(float *out, fl
 		if (KIND == 10) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[K]) : "v"((double)m));                                \
 		if (KIND == 11) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[K]) : "v"((double)c));                                \
 		if (KIND == 12) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[K]) : "v"(u[K]), "v"(m)); \
-		if (KIND == 13) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[K]) : "v"(u[(K + 1) & 7]));
+		if (KIND == 13) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[K]) : "v"(u[(K + 1) & 7]));                            \
+		if (KIND == 14) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[K]) : "v"(u[K]), "v"(u[(K + 1) & 7]) : "vcc"); \
+		if (KIND == 15) asm volatile("v_rsq_f64 %0, %0" : "+v"(d[K]));                                                     \
+		if (KIND == 16) asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %0" : "+v"(d[K]) : "v"((double)m) : "vcc");         \
+		if (KIND == 17) asm volatile("v_div_fmas_f64 %0, %0, %1, %2" : "+v"(d[K]) : "v"((double)m), "v"((double)c) : );   \
+		if (KIND == 18) asm volatile("v_div_fixup_f64 %0, %0, %1, %2" : "+v"(d[K]) : "v"((double)m), "v"((double)c));     \
+		if (KIND == 19) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(d[K]) : "v"(u[K]));                                     \
+		if (KIND == 20) asm volatile("v_lshrrev_b64 %0, 27, %0" : "+v"(q[K]));                                             \
+		if (KIND == 21) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[K]) : "v"(d[K]));                                     \
+		if (KIND == 22) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(u[K]) : "v"(u[(K + 1) & 7]));                        \
+		if (KIND == 23) asm volatile("v_sqrt_f64 %0, %0" : "+v"(d[K]));
 		REP8(OP)
 #undef OP
 	}
 	float s = 0;
-	for (int k = 0; k < 8; ++k) s += a[k] + p[k].x + p[k].y + (float)d[k] + (float)u[k];
+	for (int k = 0; k < 8; ++k) s += a[k] + p[k].x + p[k].y + (float)d[k] + (float)u[k] + (float)q[k];
 	if (s == 12345.678f) out[0] = s;
 }
 template <int KIND> static void run(const char *name, float *out) {
@@ -55,5 +65,8 @@ int main() {
 	run<4>("v_max3_f32", out); run<5>("v_min_u32", out); run<6>("v_cndmask_b32", out); run<7>("v_ldexp_f32", out);
 	run<8>("v_mul_lo_u32", out); run<9>("v_rcp_f64", out); run<10>("v_mul_f64", out); run<11>("v_add_f64", out);
 	run<12>("v_fma_mix_f32", out); run<13>("v_add_u32", out);
+	run<14>("v_mad_u64_u32", out); run<15>("v_rsq_f64", out); run<16>("v_div_scale_f64", out); run<17>("v_div_fmas_f64", out);
+	run<18>("v_div_fixup_f64", out); run<19>("v_cvt_f64_u32", out); run<20>("v_lshrrev_b64", out); run<21>("v_cvt_f32_f64", out);
+	run<22>("v_mul_hi_u32", out); run<23>("v_sqrt_f64", out);
 	return hipDeviceSynchronize() == hipSuccess ? 0 : 2;
 }
