@@ -17,6 +17,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                       cache bytes / 34.5 TB/s L2) from the algorithmic work per ray, both terms printed
   roofline_formfactor the form-factor kernel (98 % of "form-factor + solve time"): fp64 vector-ALU bound
   tile_launch         N=1 only: the frame as the 8 launches one rank of 8 issues, against the one full-frame launch
+  strong_scaling_one_frame  N>1 only: ONE 1-spp frame dealt over the ranks, ms and efficiency against the full frame on one rank
   solver / formfactor the 64 K-patch solve (synthetic F, row-sharded over the ranks) and the form-factor build
   cpu_baseline        the oracle (CPU restatement, OpenMP) on a bounded sample of the same rays, N=1 only
   cpu_baseline_radiosity  the metric's second half on the CPU: the oracle (OpenMP) on the C2 box, and the COMPILED REFERENCE's
@@ -34,7 +35,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
-FP64_PEAK_TFLOPS = 78.6        # MI355X_MICROARCH.md: peak FP64 vector
+FP64_PEAK_TFLOPS = 78.6        # AMD's published MI355X FP64 vector peak (the guide gives no fp64 vector figure) = 256 CUs x 4 SIMDs x
+                               # 16 lanes x 2 flop x 2.4 GHz, i.e. one v_fma_f64 per 4 cycles and SIMD; measured issue cost 5.1 cycles
+                               # (tools/ub/valu_rate, profiles/ab_r03.md) = 61.7 TFLOP/s attainable
 L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: L2, 8 XCDs aggregate
 # Algorithmic fp64 flop of one form-factor sample: two sample points from their hashes (2 x 24), Unit(xj − xi)
 # with its length (3 + 5 + sqrt + 3 div), the two cosines and the ray origin (5 + 6 + 6) = 77; and per ray that is shot
@@ -152,6 +155,38 @@ def main():
     launches_per_step = (spp + MAXS - 1) // MAXS
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * launches_per_step)   # average duration of one launch (HIP events)
     mrays = rays_total * args.steps / dt / 1e6
+
+    # ------------------------------------------------------------------ strong scaling: ONE 1-spp frame dealt over the N ranks
+    # (north_star's "near-linear tile scaling"; the reference's loop is one frame, rasterizer.cpp:219-233).  Every rank
+    # traces every N-th 64x64 tile of the same frame into its own buffer; no collective on the data path (the final gather of
+    # the disjoint tiles is a D2H copy per rank, not timed, as at N = 1).  efficiency = the full frame on ONE rank (measured
+    # on every rank, the slowest taken) / (N x the dealt frame).
+    strong = None
+    if world > 1:
+        def one_frame_dealt():
+            scene.primary_dev(cam, frames[0].data_ptr(), tile=TILE, tile_first=rank, tile_stride=world, stream=stream)
+
+        def one_frame_alone():
+            scene.primary_dev(cam, frames[0].data_ptr(), tile=TILE, stream=stream)
+        for fn in (one_frame_alone, one_frame_dealt):
+            for _ in range(max(1, args.warmup)):
+                fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_frame_alone()
+        torch.cuda.synchronize()
+        alone_ms = max_over_ranks((time.perf_counter() - t0) * 1e3 / args.steps)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_frame_dealt()
+        barrier()
+        dealt_ms = max_over_ranks((time.perf_counter() - t0) * 1e3 / args.steps)
+        strong = {"workload": "ONE C3 frame at 1 spp, its 64x64 tiles dealt round-robin over the %d ranks" % world,
+                  "ms_per_frame": round(dealt_ms, 4), "mrays_per_s": round(n_pix / dealt_ms / 1e3, 1),
+                  "full_frame_on_one_rank_ms": round(alone_ms, 4), "speedup": round(alone_ms / dealt_ms, 3),
+                  "efficiency": round(alone_ms / dealt_ms / world, 4), "scaling": "strong"}
 
     # traversal work of the frame (diagnostic kernel, untimed) -> roofline of the closest-hit kernel
     counts = torch.zeros(6, dtype=torch.int64, device="cuda")
@@ -326,8 +361,18 @@ def main():
         if args.ff_rows != 0:
             k = max(1, int(round((n / 12.0) ** 0.5)))
             verts, normals, light = workloads.closed_box(k, hole=0.3)
+            # one-time set-up of the radiosity path, timed: scene build (host BVH + upload), patch set
+            # (rtmi_patches_create), and below the first rtmi_form_factors_dev call (path tables on the host + the library's
+            # timing of its two kernels on up to 1024 rows)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
             box = rt.Scene(verts)
+            torch.cuda.synchronize()
+            setup_scene_s = time.perf_counter() - ts
+            ts = time.perf_counter()
             rad = rt.Radiosity(box, normals, light)
+            torch.cuda.synchronize()
+            setup_patches_s = time.perf_counter() - ts
             nb = rad.n
             ldb = (nb + 3) // 4 * 4
             r0, nr, _ = multi.rows_of_rank(nb, rank, world)
@@ -341,7 +386,11 @@ def main():
                                                   Fb[first:].data_ptr(), ldb, stream)
                 if rc != 0:
                     raise SystemExit(rt.lib.rtmi_last_error().decode())
-            build(0, min(1024, nr_s))                                                # warm-up: builds the path tables and lets the library time its two kernels
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            build(0, min(1024, nr_s))                                                # first call: builds the path tables and lets the library time its two kernels
+            torch.cuda.synchronize()
+            setup_first_call_s = time.perf_counter() - ts
             barrier()
             fe0, fe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n_launch = 0
@@ -393,6 +442,17 @@ def main():
             import zlib
             pinned = [r for r in (0, 21000, 43210, 64743) if r0 <= r < r0 + nr_s and r < ne]
             formfactor["crc32_of_pinned_rows"] = {str(r): "%08x" % zlib.crc32(Fb[r - r0, : nb].cpu().numpy().tobytes()) for r in pinned}
+            try:   # the oracle's CRCs of the same rows (oracle/gen_golden_c5_rows.py; tests/test_gpu_full_size.py asserts them too)
+                pin = json.load(open(os.path.join(ROOT, "tests", "golden", "c5_box_rows.json")))
+                if pin.get("patches") == ne:
+                    formfactor["pinned_rows_equal_the_oracle"] = all(formfactor["crc32_of_pinned_rows"][str(r)] == pin["crc32"][str(r)] for r in pinned)
+            except Exception:
+                pass
+            setup_s = max_over_ranks(setup_scene_s + setup_patches_s + setup_first_call_s)
+            formfactor["setup_seconds"] = round(setup_s, 4)
+            formfactor["setup"] = {"scene_build_and_upload": round(setup_scene_s, 4), "patch_set": round(setup_patches_s, 4),
+                                   "first_call_tables_and_kernel_choice": round(setup_first_call_s, 4),
+                                   "note": "once per scene / patch set, outside `seconds`; the first call also writes its (up to 1024) rows"}
             if not full:
                 formfactor["extrapolated_full_build_seconds"] = round(ff_s * nr / nr_s, 1)
             else:
@@ -406,6 +466,7 @@ def main():
                 Bh = rad.B[: rad.numOfElements, 0].float().cpu().numpy()
                 formfactor.update({"solve_seconds": round(sv, 4), "solve_sweeps": int(rad.stats.sweeps),
                                    "solve_rel_change": rad.stats.rel_change, "formfactor_plus_solve_seconds": round(ff_s + sv, 3),
+                                   "formfactor_plus_solve_seconds_cold": round(ff_s + sv + setup_s, 3),
                                    "B_mean": float(Bh.mean()), "B_max": float(Bh.max()),
                                    "row_sum_mean_of_local_rows": float(Fb[:, : rad.numOfElements].sum(1).mean())})
             del Fb
@@ -652,7 +713,8 @@ def main():
                                "max_leaf": int(info.max_leaf_size), "build_seconds": round(info.build_seconds, 2),
                                "device_MB": round(info.device_bytes / 1e6, 1)}},
             "roofline": roofline, "roofline_traversal": roofline_traversal, "roofline_formfactor": roofline_formfactor,
-            "tile_launch": tile_launch,
+            "roofline_note": "`roofline` is k_jacobi_sweep, the HBM-bound kernel of the metric's second half; the kernel `value` times is in roofline_traversal (bound: L2), the one that dominates form-factor + solve time in roofline_formfactor (bound: fp64 vector ALU)",
+            "tile_launch": tile_launch, "strong_scaling_one_frame": strong,
             "solver": solver, "formfactor": formfactor,
             "cpu_baseline": cpu, "cpu_baseline_radiosity": cpu_rad, "reference_so": have_ref_so, "c1_reference": c1, "frame": frame,
         }

@@ -361,16 +361,28 @@ typedef struct rtmi_solve_stats {
 	double max_change; /* max_i |B_k − B_{k-1}| at exit = max residual of B_{k-1} */
 	double seconds;    /* device time of the sweeps (HIP events) */
 	double bytes_per_sweep;
+	uint32_t accelerated_sweeps; /* how many of `sweeps` were Chebyshev steps (0: Jacobi throughout) */
+	double spectral_radius;      /* the estimate of rho(rho·F) the Chebyshev steps used (0: none was made) */
 } rtmi_solve_stats;
 
 /* exchange hook: called after every sweep with the stream the sweep ran on; must make
  * d_B (all n rows) hold every rank's rows and sum d_norms[0..1] / max d_norms[2] across ranks
- * before returning (stream-ordered).  NULL = single GPU. */
+ * before returning (stream-ordered).  NULL = single GPU.
+ * It is also called ONCE BEFORE THE FIRST SWEEP (d_B = B_0 = E, the same on every rank; d_norms = {0, 0, status}): the
+ * maximum it takes of d_norms[2] is how the ranks agree that every one of them got through its set-up — a rank that did
+ * not (hipMalloc failed) puts +inf there and EVERY rank returns -1 instead of waiting in a collective for a peer that left.
+ * A rank whose sweep fails later keeps calling the hook with +inf in d_norms[2] until the next check, where all return -1. */
 typedef int (*rtmi_exchange_fn)(void *user, float *d_B, double *d_norms, void *stream);
 
 /* Whole solve on device-resident F (rows [row0,row0+n_rows) local).  d_B [n][3] receives the
  * result (every rank gets all rows when exchange != NULL).  Stops when rel_change <= tol_rel
- * (checked every check_every sweeps) or after max_sweeps. */
+ * (checked every check_every sweeps) or after max_sweeps.
+ * The first window (check_every sweeps, at most 3) is Jacobi; from the first check on the sweeps are Chebyshev steps on the same
+ * kernel (B_{k+1} = w·J(B_k) + (1 − w)·B_{k-1}; the spectral radius of rho·F is estimated from the Jacobi sweeps' change
+ * norms): the same fixed point in about half the sweeps.  RTMI_SOLVER=jacobi in the environment keeps Jacobi throughout.
+ * tol_rel = 0: exactly max_sweeps Jacobi sweeps and no host read of the norms (rel_change / max_change come back NaN).
+ * The call allocates its scratch (hipMalloc) and synchronises the stream at every check and at the end: it cannot be
+ * captured into a graph (rtmi_radiosity_solve_noalloc_dev with tol_rel = 0 can). */
 int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows,
                              const double rho[3], const float *d_E, float *d_B, float tol_rel, uint32_t max_sweeps,
                              uint32_t check_every, rtmi_exchange_fn exchange, void *user, rtmi_solve_stats *stats,
@@ -385,7 +397,11 @@ int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t
  *   rtmi_radiosity_solve_sharded_dev   collective: every rank calls it with the same n, tolerances and check_every.
  *     Per sweep: the sweep kernel on this rank's rows, then an in-place all-gather of the ranks' blocks of B — both only
  *     enqueued on `stream`; every check_every sweeps two small all-reduces of the norms and ONE host wait.  d_B [n][3]
- *     receives all rows on every rank; stats->seconds is host wall time (sweeps, exchange and checks).
+ *     receives all rows on every rank; stats->seconds is host wall time (sweeps, exchange and checks).  It is the same loop
+ *     as rtmi_radiosity_solve_dev's (same sweeps, same Chebyshev steps, same B bit for bit).  Before the first sweep the
+ *     ranks all-reduce a status word: a rank whose set-up failed makes every rank return -1; a rank whose sweep launch fails
+ *     later still enters the window's collectives and poisons the norms, so all ranks return -1 at the next check; an RCCL
+ *     error aborts the communicator (ncclCommAbort) — it must then be destroyed and made again.
  * RCCL is loaded at run time (dlopen librccl.so.1); without it these three fail with a message, nothing else needs it. */
 #define RTMI_COMM_ID_BYTES 128
 typedef struct rtmi_comm rtmi_comm;
@@ -404,7 +420,11 @@ int rtmi_radiosity_solve_sharded_dev(rtmi_comm *, const float *d_F, uint64_t ld,
  * and no HIP events are created (stats->seconds is host wall time around the loop).  It calls no hipMalloc, hipFree or
  * other allocating routine.  Limits: n <= RTMI_NOALLOC_MAX_N and check_every <= RTMI_NOALLOC_MAX_CHECK_EVERY, otherwise -1
  * with a message.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two host threads, two
- * streams) race — serialise them.  What must start at zero (the norm windows) is cleared on the stream by each call. */
+ * streams) race — serialise them.  What must start at zero (the norm windows) is cleared on the stream by each call.
+ * With a tolerance the call reads the norms on the host at every check and waits for the stream at the end, as
+ * rtmi_radiosity_solve_dev does: such a call is REFUSED (-1) while `stream` is being captured.  With tol_rel = 0 it
+ * enqueues exactly max_sweeps Jacobi sweeps and the copy into d_B and reads nothing back; on a capturing stream it does not
+ * synchronise either — that form can be recorded into a HIP graph and replayed (tests/test_zz_no_alloc.py does). */
 #define RTMI_NOALLOC_MAX_N 131072u
 #define RTMI_NOALLOC_MAX_CHECK_EVERY 64u
 int rtmi_radiosity_solve_noalloc_dev(const float *d_F, uint64_t ld, uint32_t n, const double rho[3], const float *d_E,

@@ -57,7 +57,7 @@ class rtmi_scene_info(C.Structure):
 
 class rtmi_solve_stats(C.Structure):
     _fields_ = [("sweeps", C.c_uint32), ("rel_change", C.c_double), ("max_change", C.c_double), ("seconds", C.c_double),
-                ("bytes_per_sweep", C.c_double)]
+                ("bytes_per_sweep", C.c_double), ("accelerated_sweeps", C.c_uint32), ("spectral_radius", C.c_double)]
 
 
 class rtmi_raster(C.Structure):

@@ -19,6 +19,7 @@
 struct rtmi_comm {
 	ncclComm_t comm = nullptr;
 	int rank = 0, world = 1, device = -1;
+	bool dead = false; // an RCCL call failed and the communicator was aborted: every later call fails at once
 };
 
 namespace rtmi {
@@ -28,6 +29,7 @@ struct Rccl {
 	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
 	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // optional
 	ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 	const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -49,6 +51,7 @@ static const Rccl *rccl(const char *who) {
 	r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
 	r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
 	r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+	r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(h, "ncclCommAbort"));
 	r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
 	r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
 	r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
@@ -60,17 +63,33 @@ static const Rccl *rccl(const char *who) {
 	return &g_rccl;
 }
 
-// the 64 norm slots of a sweep (k_jacobi_sweep spreads its atomics over them) -> {Σd², Σ(B−E)²} and {max|d|}
-__global__ void k_fold_norms(const double *__restrict__ slots, uint32_t n_slots, double *__restrict__ sums, double *__restrict__ mx) {
-	const uint32_t l = threadIdx.x;
-	double a = 0.0, b = 0.0, m = 0.0;
-	if (l < n_slots) { a = slots[3 * l]; b = slots[3 * l + 1]; m = slots[3 * l + 2]; }
-	for (int off = 32; off > 0; off >>= 1) {
-		a += __shfl_xor(a, off, 64);
-		b += __shfl_xor(b, off, 64);
-		m = fmax(m, __shfl_xor(m, off, 64));
+// ---- the solve loop's exchange over RCCL (SolveExchange, rtmi_rad_device.hpp) --------------------------------------------
+struct RcclExchange {
+	rtmi_comm *c;
+	const Rccl *R;
+	uint32_t blk; // rows per rank
+};
+// An RCCL call that returns an error leaves the communicator in an unknown state: abort it, so that nothing of this rank
+// stays queued on it and later calls fail at once instead of hanging.
+static int nccl_failed(RcclExchange *x, ncclResult_t r, const char *what) {
+	const std::string msg = std::string(what) + ": " + x->R->GetErrorString(r);
+	if (!x->c->dead) {
+		x->c->dead = true;
+		if (x->R->CommAbort && x->c->comm) { (void)x->R->CommAbort(x->c->comm); x->c->comm = nullptr; }
 	}
-	if (l == 0) { sums[0] = a; sums[1] = b; mx[0] = m; }
+	return fail(msg + " (the communicator was aborted: destroy it and create a new one)");
+}
+static int rccl_gather(void *self, float *d_B_new, double *, hipStream_t st) {
+	RcclExchange *x = static_cast<RcclExchange *>(self);
+	// in place: rank r's block already sits at d_B_new + r·blk·3
+	const ncclResult_t r = x->R->AllGather(d_B_new + (size_t)x->c->rank * x->blk * 3, d_B_new, (size_t)x->blk * 3, ncclFloat, x->c->comm, st);
+	return r == ncclSuccess ? 0 : nccl_failed(x, r, "ncclAllGather");
+}
+static int rccl_reduce(void *self, double *d_red, hipStream_t st) {
+	RcclExchange *x = static_cast<RcclExchange *>(self);
+	ncclResult_t r = x->R->AllReduce(d_red, d_red, 3, ncclDouble, ncclSum, x->c->comm, st);
+	if (r == ncclSuccess) r = x->R->AllReduce(d_red + 3, d_red + 3, 1, ncclDouble, ncclMax, x->c->comm, st);
+	return r == ncclSuccess ? 0 : nccl_failed(x, r, "ncclAllReduce");
 }
 
 } // namespace rtmi
@@ -111,7 +130,8 @@ rtmi_comm *rtmi_comm_create(const uint8_t id[RTMI_COMM_ID_BYTES], int rank, int 
 
 void rtmi_comm_destroy(rtmi_comm *c) {
 	if (!c) return;
-	if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+	const Rccl *R = rccl("rtmi_comm_destroy"); // (takes the table's lock; the table exists if the communicator does)
+	if (c->comm && R && R->CommDestroy) (void)R->CommDestroy(c->comm);
 	delete c;
 }
 
@@ -121,6 +141,7 @@ int rtmi_radiosity_solve_sharded_dev(rtmi_comm *c, const float *d_F, uint64_t ld
 	const char *who = "rtmi_radiosity_solve_sharded_dev";
 	if (!c || (!d_F && n_rows) || !rho || !d_E || !d_B) return fail(std::string(who) + ": NULL argument"); // (a rank may own no rows)
 	if (n == 0) return fail(std::string(who) + ": n == 0");
+	if (c->dead || !c->comm) return fail(std::string(who) + ": the communicator was aborted after an RCCL error; destroy it and create a new one");
 	int dev = -1;
 	if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return fail(std::string(who) + ": the communicator was created on another device");
 	const Rccl *R = rccl(who);
@@ -132,62 +153,23 @@ int rtmi_radiosity_solve_sharded_dev(rtmi_comm *c, const float *d_F, uint64_t ld
 		return fail(std::string(who) + ": rows [row0, row0 + n_rows) are not this rank's block of ceil(n / world) rows");
 	if ((uint64_t)row0 + n_rows > n) return fail(std::string(who) + ": row range exceeds n");
 	if (check_every == 0) check_every = 1;
-	hipStream_t st = (hipStream_t)stream;
+	// From here on every rank reaches solve_loop's status agreement, whatever happens to it: a failed allocation is handed
+	// in as setup_rc and told to the others there.  (The small block first: it carries the word the ranks agree on.)
 	const size_t n_pad = (size_t)blk * W, vb = sizeof(float) * 3 * n_pad;
+	if (n_pad > 0xffffffffull) return fail(std::string(who) + ": n too large");
 	float *buf[2] = {nullptr, nullptr};
-	double *d_norms = nullptr, *d_red = nullptr; // check_every × 64 slots × 3; {Σd², Σ(B−E)², max|d|}
-	const size_t nb = 3 * sizeof(double) * kNormSlots;
+	double *d_norms = nullptr; // check_every windows of 64 slots × 3, then the 4 words of a check
+	const size_t norm_doubles = 3 * (size_t)kNormSlots * check_every;
 	int rc = 0;
-	if (hipMalloc(&buf[0], vb) != hipSuccess || hipMalloc(&buf[1], vb) != hipSuccess || hipMalloc(&d_norms, nb * check_every) != hipSuccess ||
-	    hipMalloc(&d_red, 3 * sizeof(double)) != hipSuccess)
+	if (hipMalloc(&d_norms, sizeof(double) * (norm_doubles + 4)) != hipSuccess) d_norms = nullptr;
+	if (!d_norms || env_uint("RTMI_DEBUG_FAIL_SOLVE_SETUP", 0) || hipMalloc(&buf[0], vb) != hipSuccess || hipMalloc(&buf[1], vb) != hipSuccess)
 		rc = fail(std::string(who) + ": hipMalloc failed");
-	auto nccl_ok = [&](ncclResult_t r, const char *what) { return r == ncclSuccess ? 0 : fail(std::string(who) + ": " + what + ": " + R->GetErrorString(r)); };
-	uint32_t sweeps = 0;
-	double rel = INFINITY, mx = INFINITY;
-	int at = 0;
-	const auto t0 = std::chrono::steady_clock::now();
-	if (!rc) {
-		// B_0 = E (Render2/radiosity.cpp:506-509); the padding rows behind n stay zero in both vectors
-		if (hipMemsetAsync(buf[0], 0, vb, st) != hipSuccess || hipMemsetAsync(buf[1], 0, vb, st) != hipSuccess ||
-		    hipMemcpyAsync(buf[0], d_E, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess)
-			rc = fail(std::string(who) + ": initialising B failed");
-	}
-	while (!rc && sweeps < max_sweeps) {
-		const uint32_t k = std::min(check_every, max_sweeps - sweeps);
-		if (hipMemsetAsync(d_norms, 0, nb * k, st) != hipSuccess) { rc = fail(std::string(who) + ": memset failed"); break; }
-		for (uint32_t i = 0; i < k && !rc; ++i) { // enqueue only: sweep, gather, sweep, gather, ...
-			float *Bo = buf[(at + i) & 1], *Bn = buf[(at + i + 1) & 1];
-			rc = sweep_launch_slots(d_F, ld, n, row0, n_rows, rho, d_E, Bo, Bn, d_norms + 3 * kNormSlots * i, kNormSlots, st);
-			// in place: rank r's block already sits at Bn + r·blk·3
-			if (!rc) rc = nccl_ok(R->AllGather(Bn + (size_t)c->rank * blk * 3, Bn, (size_t)blk * 3, ncclFloat, c->comm, st), "ncclAllGather");
-		}
-		if (rc) break;
-		at = (at + (int)k) & 1;
-		sweeps += k;
-		hipLaunchKernelGGL(k_fold_norms, dim3(1), dim3(64), 0, st, d_norms + 3 * kNormSlots * (k - 1), kNormSlots, d_red, d_red + 2);
-		if (launch_check(who)) { rc = -1; break; }
-		rc = nccl_ok(R->AllReduce(d_red, d_red, 2, ncclDouble, ncclSum, c->comm, st), "ncclAllReduce");
-		if (!rc) rc = nccl_ok(R->AllReduce(d_red + 2, d_red + 2, 1, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
-		double h[3];
-		if (!rc && (hipMemcpyAsync(h, d_red, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
-			rc = fail(std::string(who) + ": reading the norms failed: " + hipGetErrorString(hipGetLastError()));
-		if (rc) break;
-		rel = h[1] > 0.0 ? std::sqrt(h[0] / h[1]) : 0.0;
-		mx = h[2];
-		if (rel <= (double)tol_rel) break; // the same numbers on every rank: every rank stops at the same sweep
-	}
-	if (!rc && (hipMemcpyAsync(d_B, buf[at], sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
-		rc = fail(std::string(who) + ": copying B out failed");
-	if (!rc && stats) {
-		stats->sweeps = sweeps;
-		stats->rel_change = rel;
-		stats->max_change = mx;
-		stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); // wall: sweeps + exchange + checks
-		stats->bytes_per_sweep = 4.0 * (double)n_rows * (double)n;
-	}
+	RcclExchange xs = {c, R, blk};
+	const SolveExchange X = {&xs, rccl_gather, rccl_reduce, false};
+	rc = solve_loop(who, d_F, ld, n, (uint32_t)n_pad, row0, n_rows, rho, d_E, d_B, tol_rel, max_sweeps, check_every, &X, stats, (hipStream_t)stream,
+	                buf[0], buf[1], d_norms, kNormSlots, d_norms ? d_norms + norm_doubles : nullptr, nullptr, nullptr, rc);
 	for (float *b : buf) if (b) (void)hipFree(b);
 	if (d_norms) (void)hipFree(d_norms);
-	if (d_red) (void)hipFree(d_red);
 	return rc;
 }
 

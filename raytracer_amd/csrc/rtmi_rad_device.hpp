@@ -89,8 +89,30 @@ __device__ __forceinline__ D3 sample_point(const double *__restrict__ e, uint64_
 
 constexpr uint32_t kNormSlots = 64; // k_jacobi_sweep spreads its norm atomics over this many triples
 // one Jacobi sweep (rtmi_radiosity.hip); block b adds its norms to triple b % slots of d_norms
+// (ca, cb) != (1, 0): B_new = B_old + ca·(J(B_old) − B_old) + cb·(B_old − what d_B_new held), J(B) = E + rho·F·B — the Chebyshev step of solve_loop
 int sweep_launch_slots(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3], const float *d_E,
-                       const float *d_B_old, float *d_B_new, double *d_norms, uint32_t slots, void *stream);
+                       const float *d_B_old, float *d_B_new, double *d_norms, uint32_t slots, void *stream, double ca = 1.0, double cb = 0.0);
+
+// How the solve loop talks to the other ranks.  Two providers: the caller's rtmi_exchange_fn (rtmi_radiosity_solve_dev) and
+// the library's own RCCL communicator (rtmi_comm.hip); a single-GPU solve passes none.
+struct SolveExchange {
+	void *self;
+	// after every sweep, stream-ordered: make d_B_new hold every rank's rows.  A provider whose gather also reduces the sweep's
+	// norm triple {Σd², Σ(B−E)², max|d|} across the ranks in place says so with triples_are_global.
+	int (*gather)(void *self, float *d_B_new, double *d_triple, hipStream_t st);
+	// at a check, stream-ordered: d_red = {Σd² last sweep, Σ(B−E)² last sweep, Σd² sweep before, max|d| last sweep} -> sums and
+	// maximum over the ranks, in place (NULL when triples_are_global: nothing is left to reduce)
+	int (*reduce)(void *self, double *d_red, hipStream_t st);
+	bool triples_are_global;
+};
+// The solve loop behind rtmi_radiosity_solve_dev / _noalloc_dev / _sharded_dev (rtmi_radiosity.hip).  buf0 / buf1: the two
+// ping-pong vectors of n_pad >= n rows (buf0 may be d_B itself when n_pad == n); d_norms: check_every windows of `slots`
+// triples; d_red: 4 doubles; setup_rc != 0: this rank's set-up failed — the loop tells the other ranks before anyone enters
+// a collective, and every rank returns -1.
+int solve_loop(const char *who, const float *d_F, uint64_t ld, uint32_t n, uint32_t n_pad, uint32_t row0, uint32_t n_rows, const double rho[3],
+               const float *d_E, float *d_B, float tol_rel, uint32_t max_sweeps, uint32_t check_every, const SolveExchange *X,
+               rtmi_solve_stats *stats, hipStream_t run, float *buf0, float *buf1, double *d_norms, uint32_t slots, double *d_red,
+               hipEvent_t e0, hipEvent_t e1, int setup_rc);
 
 inline int check_patches(const rtmi_patches *p, const char *who) {
 	if (!p) return fail(std::string(who) + ": patches is NULL");

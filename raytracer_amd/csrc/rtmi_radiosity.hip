@@ -7,6 +7,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -53,7 +54,7 @@ __device__ __forceinline__ float4 load_F4(const float *p) {
 __global__ __launch_bounds__(kJBlock) void k_jacobi_sweep(const float *__restrict__ F, uint64_t ld, uint32_t n, uint32_t row0,
                                                          uint32_t n_rows, double rho0, double rho1, double rho2,
                                                          const float *__restrict__ E, const float *__restrict__ Bold,
-                                                         float *__restrict__ Bnew, double *__restrict__ norms, uint32_t slots) {
+                                                         float *Bnew, double *__restrict__ norms, uint32_t slots, double ca, double cb) {
 	__shared__ double red[kJWaves][kRows][3];
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const uint32_t r0 = blockIdx.x * kRows; // local row
@@ -115,8 +116,13 @@ __global__ __launch_bounds__(kJBlock) void k_jacobi_sweep(const float *__restric
 			const size_t gi = 3 * (size_t)(row0 + r0 + r) + ch;
 			const double rho = ch == 0 ? rho0 : (ch == 1 ? rho1 : rho2);
 			const double e = (double)E[gi];
-			const float bn = (float)(e + rho * s);
-			const double d = (double)bn - (double)Bold[gi];
+			// (ca, cb) = (1, 0): the Jacobi update.  Otherwise the Chebyshev step of solve_loop:
+			// B_new = B_old + ca·(J(B_old) − B_old) + cb·(B_old − B_prev), where B_prev is what the ping-pong partner being
+			// written still holds (the iterate before B_old).
+			const double jac = e + rho * s;
+			const double bo = (double)Bold[gi];
+			const float bn = (ca == 1.0 && cb == 0.0) ? (float)jac : (float)(bo + ca * (jac - bo) + cb * (bo - (double)Bnew[gi]));
+			const double d = (double)bn - bo;
 			Bnew[gi] = bn;
 			d2 = d * d;
 			b2 = ((double)bn - e) * ((double)bn - e);
@@ -438,7 +444,8 @@ static bool display_uses_bvh(const rtmi_patches *P) {
 constexpr size_t kScratchTmpBytes = sizeof(float) * 3 * (size_t)RTMI_NOALLOC_MAX_N;                                   // 1.5 MiB
 constexpr size_t kScratchNormBytes = 3 * sizeof(double) * (size_t)kNormSlots * RTMI_NOALLOC_MAX_CHECK_EVERY;           // 96 KiB
 static_assert(kScratchTmpBytes % 256 == 0, "the norms start on a 256-byte boundary");
-static __device__ __align__(256) unsigned char scratch[kScratchTmpBytes + kScratchNormBytes];
+constexpr size_t kScratchRedBytes = 256;                                                                                 // the 4 doubles a convergence check reads
+static __device__ __align__(256) unsigned char scratch[kScratchTmpBytes + kScratchNormBytes + kScratchRedBytes];
 
 constexpr int kMaxDevices = 64;
 static std::mutex g_scratch_mutex;
@@ -463,7 +470,7 @@ using namespace rtmi;
 
 // One sweep; the three norms are accumulated into `slots` triples (block b into triple b % slots), which the caller adds up.
 int rtmi::sweep_launch_slots(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3],
-                        const float *d_E, const float *d_B_old, float *d_B_new, double *d_norms, uint32_t slots, void *stream) {
+                        const float *d_E, const float *d_B_old, float *d_B_new, double *d_norms, uint32_t slots, void *stream, double ca, double cb) {
 	const char *who = "rtmi_jacobi_sweep_dev";
 	if (n_rows == 0) return 0;
 	if (!d_F || !rho || !d_E || !d_B_old || !d_B_new || !d_norms) return fail(std::string(who) + ": NULL argument");
@@ -474,7 +481,7 @@ int rtmi::sweep_launch_slots(const float *d_F, uint64_t ld, uint32_t n, uint32_t
 	if (d_B_old == d_B_new) return fail(std::string(who) + ": Jacobi needs distinct B_old and B_new");
 	const uint32_t grid = (n_rows + kRows - 1) / kRows;
 	hipLaunchKernelGGL(k_jacobi_sweep, dim3(grid), dim3(kJBlock), 0, (hipStream_t)stream, d_F, ld, n, row0, n_rows, rho[0], rho[1],
-	                   rho[2], d_E, d_B_old, d_B_new, d_norms, slots);
+	                   rho[2], d_E, d_B_old, d_B_new, d_norms, slots, ca, cb);
 	return launch_check(who);
 }
 
@@ -584,78 +591,201 @@ int rtmi_jacobi_sweep_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t ro
 	return sweep_launch_slots(d_F, ld, n, row0, n_rows, rho, d_E, d_B_old, d_B_new, d_norms, 1, stream);
 }
 
-// The Jacobi loop shared by rtmi_radiosity_solve_dev (which allocates d_tmp / d_norms per call) and
-// rtmi_radiosity_solve_noalloc_dev (which brings them from the library's static device array).  e0/e1: HIP events that time
-// the sweeps, or NULL (then stats->seconds is host wall time around the loop, synchronisation included).
-static int solve_loop(const char *who, const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3],
-                      const float *d_E, float *d_B, float tol_rel, uint32_t max_sweeps, uint32_t check_every, rtmi_exchange_fn exchange,
-                      void *user, rtmi_solve_stats *stats, hipStream_t run, float *d_tmp, double *d_norms, uint32_t slots,
-                      hipEvent_t e0, hipEvent_t e1) {
-	const size_t vb = sizeof(float) * 3 * (size_t)n;
+} // extern "C"
+
+namespace rtmi {
+
+// the norm slots of the last sweep of a window (and of the one before it) -> out[4] = {Σd² last, Σ(B−E)² last, Σd² before,
+// max|d| last}; slots are added in index order by one lane — the order the host used to add them in, the same on every path.
+// `poison` != 0 (this rank failed): the maximum becomes +inf, which every rank reads after the reduction.
+__global__ void k_fold_norms(const double *__restrict__ last, const double *__restrict__ before, uint32_t slots, int poison, double *__restrict__ out) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	double a = 0.0, b = 0.0, c = 0.0, m = 0.0;
+	for (uint32_t q = 0; q < slots; ++q) {
+		a += last[3 * q];
+		b += last[3 * q + 1];
+		m = fmax(m, last[3 * q + 2]);
+		if (before) c += before[3 * q];
+	}
+	out[0] = a; out[1] = b; out[2] = c;
+	out[3] = poison ? (double)INFINITY : m;
+}
+// a rank that failed marks the triple its exchange callback is about to reduce (max over ranks): +inf reaches every rank
+__global__ void k_poison_triple(double *__restrict__ t) {
+	if (threadIdx.x == 0 && blockIdx.x == 0) t[2] = (double)INFINITY;
+}
+
+// The loop shared by rtmi_radiosity_solve_dev (allocates its vectors per call), rtmi_radiosity_solve_noalloc_dev (brings them
+// from the library's static device array) and rtmi_radiosity_solve_sharded_dev (RCCL exchange, rtmi_comm.hip).
+//   * Sweeps: Jacobi, B <- E + rho∘(F·B), for the first window (at most 3 sweeps); from the first check on (RTMI_SOLVER=jacobi
+//     keeps Jacobi throughout) Chebyshev semi-iteration on the same sweep kernel:
+//         B_{k+1} = B_k + ca_k·(J(B_k) − B_k) + cb_k·(B_k − B_{k-1})
+//     with the standard recurrence for a spectrum of rho·F inside [a, b]: theta = 1 − (a + b)/2, delta = (b − a)/2,
+//     first step ca = 1/theta, cb = 0, r_0 = delta/theta; then r_k = 1/(2·theta/delta − r_{k-1}), ca = 2·r_k/delta,
+//     cb = r_k·r_{k-1}.  b is the ratio of the change norms of the last two Jacobi sweeps (a power-iteration estimate of the
+//     spectral radius); a = −b/4: form-factor matrices are similar to symmetric ones (reciprocity A_i·F_ij = A_j·F_ji), their
+//     eigenvalues are real, and the negative ones measured on boxes of 3.8 K and 19 K patches are small — [−b/4, b] gave the
+//     fewest sweeps there (15 against Jacobi's 24 to 1e-4; [−b, b]: 19, [0, b]: 19-23) and on the synthetic matrix (11
+//     against 20), tools/quick_solver.py, profiles/ab_r03.md.  A wrong interval only slows the iteration (it converges for
+//     any eigenvalue above a + b − 1), and if the relative change GROWS from one check to the next the loop goes back to
+//     Jacobi for good.  The sweep streams F from HBM at 0.8 of the peak either way, so time to tolerance falls with the
+//     sweep count.  Same fixed point as the reference's shooting iteration (Render2/radiosity.cpp:483-563).
+//   * Ranks: before the first sweep the ranks agree on a status word through the exchange (a rank whose set-up failed makes
+//     EVERY rank return -1 instead of leaving its peers in a collective); a rank whose sweep launch fails later still takes
+//     part in the window's exchanges and poisons the norms, so all ranks fail together at the next check.
+//   * tol_rel == 0: exactly max_sweeps Jacobi sweeps, no host read and no synchronisation inside the loop (the norms stay on
+//     the device) — the form a HIP graph capture can record; with a tolerance the call reads norms on the host at every check
+//     and is refused while the stream is capturing.
+int solve_loop(const char *who, const float *d_F, uint64_t ld, uint32_t n, uint32_t n_pad, uint32_t row0, uint32_t n_rows, const double rho[3],
+               const float *d_E, float *d_B, float tol_rel, uint32_t max_sweeps, uint32_t check_every, const SolveExchange *X,
+               rtmi_solve_stats *stats, hipStream_t run, float *buf0, float *buf1, double *d_norms, uint32_t slots, double *d_red,
+               hipEvent_t e0, hipEvent_t e1, int setup_rc) {
+	const size_t vb = sizeof(float) * 3 * (size_t)n, vpad = sizeof(float) * 3 * (size_t)n_pad;
 	const size_t nb = 3 * sizeof(double) * slots;
-	int rc = 0;
-	// B_0 = E (Render2/radiosity.cpp:506-509)
-	if (hipMemcpyAsync(d_B, d_E, vb, hipMemcpyDeviceToDevice, run) != hipSuccess) return fail(std::string(who) + ": copy failed");
-	float *buf[2] = {d_B, d_tmp};
+	const bool fixed = tol_rel == 0.0f; // exactly max_sweeps sweeps, nothing read back
+	hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+	const bool capturing = hipStreamIsCapturing(run, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+	if (capturing && (!fixed || X))
+		return fail(std::string(who) + ": the stream is being captured into a graph; only tol_rel = 0 (a fixed number of sweeps, no host read) without an exchange can be captured");
+	const char *solver = std::getenv("RTMI_SOLVER");
+	const bool want_cheb = !fixed && !(solver && std::strcmp(solver, "jacobi") == 0);
+	int rc = setup_rc;
+	if (!rc && !d_red && !fixed) rc = fail(std::string(who) + ": internal: no reduction buffer");
+	// B_0 = E (Render2/radiosity.cpp:506-509); rows behind n (the all-gather's padding) stay zero in both vectors
+	if (!rc) {
+		bool ok = true;
+		if (n_pad > n) ok = hipMemsetAsync(buf0, 0, vpad, run) == hipSuccess && hipMemsetAsync(buf1, 0, vpad, run) == hipSuccess;
+		ok = ok && hipMemcpyAsync(buf0, d_E, vb, hipMemcpyDeviceToDevice, run) == hipSuccess;
+		if (!ok) rc = fail(std::string(who) + ": initialising B failed");
+	}
+	double h[4] = {0.0, 0.0, 0.0, 0.0};
+	// ---- the ranks agree on a status before anyone enters the loop's collectives --------------------------------------
+	if (X) {
+		if (!d_red || !d_norms) return fail(std::string(who) + ": could not allocate the words the ranks agree on (this rank fails alone)");
+		int xrc = 0;
+		if (X->triples_are_global) { // the caller's callback: its reduction of a norm triple carries the word (max over ranks)
+			xrc = hipMemsetAsync(d_norms, 0, 3 * sizeof(double), run) != hipSuccess;
+			if (!xrc && rc) hipLaunchKernelGGL(k_poison_triple, dim3(1), dim3(64), 0, run, d_norms);
+			// (B_0 = E on every rank, so gathering it changes nothing; a rank without vectors hands over d_B)
+			if (!xrc) xrc = X->gather(X->self, rc ? d_B : buf0, d_norms, run);
+			if (!xrc) xrc = hipMemcpyAsync(h, d_norms, 3 * sizeof(double), hipMemcpyDeviceToHost, run) != hipSuccess || hipStreamSynchronize(run) != hipSuccess;
+			h[3] = h[2];
+		} else {
+			xrc = hipMemsetAsync(d_red, 0, 4 * sizeof(double), run) != hipSuccess;
+			if (!xrc && rc) hipLaunchKernelGGL(k_poison_triple, dim3(1), dim3(64), 0, run, d_red + 1); // d_red[3]
+			if (!xrc) xrc = X->reduce(X->self, d_red, run);
+			if (!xrc) xrc = hipMemcpyAsync(h, d_red, 4 * sizeof(double), hipMemcpyDeviceToHost, run) != hipSuccess || hipStreamSynchronize(run) != hipSuccess;
+		}
+		if (xrc) return rc ? -1 : fail(std::string(who) + ": the exchange failed while the ranks agreed on their status");
+		if (rc) return -1; // (the message of this rank's own failure stands)
+		if (!(h[3] == 0.0)) return fail(std::string(who) + ": another rank failed its set-up; every rank returns");
+	} else if (rc) return -1;
+	float *buf[2] = {buf0, buf1};
 	int at = 0; // buf[at] holds the current B
-	uint32_t sweeps = 0;
-	double rel = INFINITY, mx = INFINITY;
+	uint32_t sweeps = 0, cheb_k = 0, accelerated = 0;
+	double rel = fixed ? NAN : INFINITY, mx = fixed ? NAN : INFINITY, rel_prev = INFINITY, d2_prev_check = 0.0, radius = 0.0;
+	double theta = 1.0, delta = 1.0, rho_prev = 0.0; // Chebyshev recurrence: centre and half-width of the spectrum of I − rho·F
+	bool cheb = false;
+	int poison = 0;
 	const auto w0 = std::chrono::steady_clock::now();
 	if (e0) (void)hipEventRecord(e0, run);
-	// one window: zero its norms, k sweeps
-	auto window = [&](uint32_t k, int from, hipStream_t s) -> int {
-		if (hipMemsetAsync(d_norms, 0, nb * k, s) != hipSuccess) return fail(std::string(who) + ": memset failed");
+	while (sweeps < max_sweeps) {
+		// (the first window is at most three sweeps when Chebyshev steps may follow: the third sweep's change against the
+		// second's is estimate enough, and every Jacobi sweep after it is one that could have been a faster step)
+		const uint32_t k = std::min(want_cheb && sweeps == 0 ? std::min(check_every, 3u) : check_every, max_sweeps - sweeps);
+		if (hipMemsetAsync(d_norms, 0, nb * k, run) != hipSuccess) poison = fail(std::string(who) + ": memset failed");
 		for (uint32_t i = 0; i < k; ++i) {
-			if (sweep_launch_slots(d_F, ld, n, row0, n_rows, rho, d_E, buf[(from + i) & 1], buf[(from + i + 1) & 1], d_norms + 3 * slots * i, slots, s)) return -1;
-			if (exchange && exchange(user, buf[(from + i + 1) & 1], d_norms + 3 * slots * i, s) != 0) return fail(std::string(who) + ": exchange callback failed");
+			double ca = 1.0, cb = 0.0;
+			if (cheb) { // the first step (cb = 0) starts the recurrence from the current iterate
+				++cheb_k;
+				if (cheb_k == 1) { ca = 1.0 / theta; rho_prev = delta / theta; }
+				else {
+					const double r = 1.0 / (2.0 * theta / delta - rho_prev);
+					ca = 2.0 * r / delta;
+					cb = r * rho_prev;
+					rho_prev = r;
+				}
+				++accelerated;
+			}
+			float *Bo = buf[(at + i) & 1], *Bn = buf[(at + i + 1) & 1];
+			double *triple = d_norms + 3 * slots * i;
+			if (!poison && sweep_launch_slots(d_F, ld, n, row0, n_rows, rho, d_E, Bo, Bn, triple, slots, run, ca, cb)) poison = -1;
+			if (X) { // a rank that failed keeps its appointments: its peers must not wait in a collective for ever
+				if (poison && X->triples_are_global) hipLaunchKernelGGL(k_poison_triple, dim3(1), dim3(64), 0, run, triple);
+				if (X->gather(X->self, Bn, triple, run) != 0) return fail(std::string(who) + ": the exchange failed after sweep " + std::to_string(sweeps + i + 1) + (g_err.empty() ? "" : ": " + g_err));
+			} else if (poison) return -1;
 		}
-		return 0;
-	};
-	while (!rc && sweeps < max_sweeps) {
-		const uint32_t k = std::min(check_every, max_sweeps - sweeps);
-		rc = window(k, at, run);
-		if (rc) break;
 		at = (at + (int)k) & 1;
 		sweeps += k;
-		double hs[3 * kNormSlots], h[3] = {0.0, 0.0, 0.0};
-		if (hipMemcpyAsync(hs, d_norms + 3 * slots * (k - 1), nb, hipMemcpyDeviceToHost, run) != hipSuccess || hipStreamSynchronize(run) != hipSuccess) {
-			rc = fail(std::string(who) + ": reading the norms failed: " + hipGetErrorString(hipGetLastError()));
-			break;
+		if (fixed) {
+			if (poison) return -1;
+			continue;
 		}
-		for (uint32_t q = 0; q < slots; ++q) {
-			h[0] += hs[3 * q];
-			h[1] += hs[3 * q + 1];
-			h[2] = std::max(h[2], hs[3 * q + 2]);
-		}
+		hipLaunchKernelGGL(k_fold_norms, dim3(1), dim3(64), 0, run, d_norms + 3 * slots * (k - 1), k >= 2 ? d_norms + 3 * slots * (k - 2) : (const double *)nullptr,
+		                   slots, poison, d_red);
+		if (X && X->reduce && X->reduce(X->self, d_red, run) != 0) return fail(std::string(who) + ": the exchange failed at the check after sweep " + std::to_string(sweeps) + (g_err.empty() ? "" : ": " + g_err));
+		if (hipMemcpyAsync(h, d_red, sizeof h, hipMemcpyDeviceToHost, run) != hipSuccess || hipStreamSynchronize(run) != hipSuccess)
+			return fail(std::string(who) + ": reading the norms failed: " + hipGetErrorString(hipGetLastError()));
+		if (poison) return -1;
+		if (!(h[3] < INFINITY)) return fail(std::string(who) + ": a rank failed during the sweeps, or B is no longer finite; every rank returns");
 		rel = h[1] > 0.0 ? std::sqrt(h[0] / h[1]) : 0.0;
-		mx = h[2];
+		mx = h[3];
 		if (rel <= (double)tol_rel) break;
+		const double d2_before = k >= 2 ? h[2] : d2_prev_check;
+		if (cheb && rel > rel_prev) { // never seen on a form-factor matrix; an iteration matrix with far-from-real eigenvalues could do it
+			cheb = false;
+		} else if (want_cheb && !cheb && cheb_k == 0 && sweeps >= 3 && d2_before > 0.0 && h[0] > 0.0) {
+			// (rounded up to a multiple of 2^-10: any b near the radius serves, and the sums it comes from are added in an order
+			// that differs between runs and between rank counts — the rounding makes the steps, hence B, reproducible)
+			radius = std::ceil(std::sqrt(h[0] / d2_before) * 1024.0) / 1024.0;
+			if (radius > 0.0 && radius < 0.9999) {
+				// spectrum of rho·F taken to lie in [low·b, b] (low = −1/4; RTMI_CHEB_LOW_PERCENT overrides, −100 = symmetric)
+				const char *lp = std::getenv("RTMI_CHEB_LOW_PERCENT");
+				const double low = lp && *lp ? std::max(-1.0, std::min(0.5, std::atof(lp) / 100.0)) : -0.25;
+				cheb = true;
+				theta = 1.0 - 0.5 * (low + 1.0) * radius;
+				delta = 0.5 * (1.0 - low) * radius;
+			}
+		}
+		rel_prev = rel;
+		d2_prev_check = h[0];
 	}
-	if (!rc) {
-		if (e1) (void)hipEventRecord(e1, run);
-		if (at != 0 && hipMemcpyAsync(d_B, buf[at], vb, hipMemcpyDeviceToDevice, run) != hipSuccess) rc = fail(std::string(who) + ": copy failed");
-		if (!rc && hipStreamSynchronize(run) != hipSuccess) rc = fail(std::string(who) + ": synchronize failed: " + hipGetErrorString(hipGetLastError()));
-	}
-	if (!rc && stats) {
+	if (e1) (void)hipEventRecord(e1, run);
+	if (buf[at] != d_B && hipMemcpyAsync(d_B, buf[at], vb, hipMemcpyDeviceToDevice, run) != hipSuccess) return fail(std::string(who) + ": copy failed");
+	if (!capturing && hipStreamSynchronize(run) != hipSuccess) return fail(std::string(who) + ": synchronize failed: " + hipGetErrorString(hipGetLastError()));
+	if (stats) {
 		float ms = 0.f;
-		if (e0 && e1) (void)hipEventElapsedTime(&ms, e0, e1);
+		if (e0 && e1 && !capturing) (void)hipEventElapsedTime(&ms, e0, e1);
 		else ms = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() * 1e3);
 		stats->sweeps = sweeps;
 		stats->rel_change = rel;
 		stats->max_change = mx;
 		stats->seconds = ms * 1e-3;
 		stats->bytes_per_sweep = 4.0 * (double)n_rows * (double)n;
+		stats->accelerated_sweeps = accelerated;
+		stats->spectral_radius = radius;
 	}
-	return rc;
+	return 0;
 }
+
+} // namespace rtmi
+
+extern "C" {
 
 static int solve_args(const char *who, const float *d_F, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3], const float *d_E,
                       const float *d_B, rtmi_exchange_fn exchange) {
-	if (!d_F || !rho || !d_E || !d_B) return fail(std::string(who) + ": NULL argument");
+	if ((!d_F && n_rows) || !rho || !d_E || !d_B) return fail(std::string(who) + ": NULL argument");
 	if (n == 0) return fail(std::string(who) + ": n == 0");
+	if ((uint64_t)row0 + n_rows > n) return fail(std::string(who) + ": row range exceeds n");
 	// Without an exchange nobody fills the rows of B this call does not own: a partial row range would iterate on garbage.
 	if (!exchange && (row0 != 0 || n_rows != n)) return fail(std::string(who) + ": a partial row range needs an exchange callback");
 	return 0;
+}
+
+struct CallbackExchange { rtmi_exchange_fn fn; void *user; };
+static int callback_gather(void *self, float *d_B_new, double *d_triple, hipStream_t st) {
+	const CallbackExchange *c = static_cast<const CallbackExchange *>(self);
+	return c->fn(c->user, d_B_new, d_triple, st) != 0 ? fail("the exchange callback returned an error") : 0;
 }
 
 int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t row0, uint32_t n_rows, const double rho[3],
@@ -664,20 +794,25 @@ int rtmi_radiosity_solve_dev(const float *d_F, uint64_t ld, uint32_t n, uint32_t
 	const char *who = "rtmi_radiosity_solve_dev";
 	if (solve_args(who, d_F, n, row0, n_rows, rho, d_E, d_B, exchange)) return -1;
 	if (check_every == 0) check_every = 1;
-	float *d_tmp = nullptr;
-	// Norms: per sweep of a window of check_every sweeps, `slots` triples (summed on the host; one triple when an exchange
-	// callback reduces them across ranks).  The last sweep's are the ones read.
+	// Norms: per sweep of a window of check_every sweeps, `slots` triples (k_jacobi_sweep spreads its atomics over them; one
+	// triple when an exchange callback reduces it across the ranks after every sweep), + the 4 words a check reads.
 	const uint32_t slots = exchange ? 1u : kNormSlots;
 	double *d_norms = nullptr;
+	float *d_tmp = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	int rc = 0;
-	if (hipMalloc(&d_tmp, sizeof(float) * 3 * (size_t)n) != hipSuccess || hipMalloc(&d_norms, 3 * sizeof(double) * slots * check_every) != hipSuccess)
+	// (the small block first: it also carries the status word the ranks agree on, so a rank that then fails to get its vector
+	// can still say so; RTMI_DEBUG_FAIL_SOLVE_SETUP=1 makes this rank fail here — tests)
+	if (hipMalloc(&d_norms, 3 * sizeof(double) * slots * check_every + 4 * sizeof(double)) != hipSuccess) d_norms = nullptr;
+	if (!d_norms || env_uint("RTMI_DEBUG_FAIL_SOLVE_SETUP", 0) || hipMalloc(&d_tmp, sizeof(float) * 3 * (size_t)n) != hipSuccess)
 		rc = fail(std::string(who) + ": hipMalloc failed");
 	if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail(std::string(who) + ": hipEventCreate failed");
 	// (A hipGraph of one window was measured at 3 816 patches: 28.5 vs 28.6 µs per sweep — the launches already run back to
 	// back on the stream and the sweep itself takes the time — and is not used.)
-	if (!rc) rc = solve_loop(who, d_F, ld, n, row0, n_rows, rho, d_E, d_B, tol_rel, max_sweeps, check_every, exchange, user, stats,
-	                         (hipStream_t)stream, d_tmp, d_norms, slots, e0, e1);
+	CallbackExchange cb = {exchange, user};
+	const SolveExchange X = {&cb, callback_gather, nullptr, true};
+	rc = solve_loop(who, d_F, ld, n, n, row0, n_rows, rho, d_E, d_B, tol_rel, max_sweeps, check_every, exchange ? &X : nullptr, stats,
+	                (hipStream_t)stream, d_B, d_tmp, d_norms, slots, d_norms ? d_norms + 3 * (size_t)slots * check_every : nullptr, e0, e1, rc);
 	if (e0) (void)hipEventDestroy(e0);
 	if (e1) (void)hipEventDestroy(e1);
 	if (d_tmp) (void)hipFree(d_tmp);
@@ -699,8 +834,9 @@ int rtmi_radiosity_solve_noalloc_dev(const float *d_F, uint64_t ld, uint32_t n, 
 	if (!base) return -1;
 	float *d_tmp = reinterpret_cast<float *>(base);                       // B ping-pong partner: fully written by sweep 1 before it is read
 	double *d_norms = reinterpret_cast<double *>(base + kScratchTmpBytes); // zeroed per window by solve_loop
-	return solve_loop(who, d_F, ld, n, 0, n, rho, d_E, d_B, tol_rel, max_sweeps, check_every, nullptr, nullptr, stats, (hipStream_t)stream,
-	                  d_tmp, d_norms, kNormSlots, nullptr, nullptr);
+	double *d_red = reinterpret_cast<double *>(base + kScratchTmpBytes + kScratchNormBytes); // the 4 words of a check
+	return solve_loop(who, d_F, ld, n, n, 0, n, rho, d_E, d_B, tol_rel, max_sweeps, check_every, nullptr, stats, (hipStream_t)stream,
+	                  d_B, d_tmp, d_norms, kNormSlots, d_red, nullptr, nullptr, 0);
 }
 
 int rtmi_radiosity_trace_dev(rtmi_patches *P, const double *d_vertex_radiosity, const rtmi_ray *d_rays, uint64_t n, double *d_rgb,

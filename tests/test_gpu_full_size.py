@@ -171,6 +171,47 @@ def test_c5_form_factor_rows_of_the_64k_box_equal_the_oracle(rt, oracle):
     one = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=21000, n_rows=1).cpu().numpy()[0]
     assert np.array_equal(blk[21000 - 20480], one)
     assert rt.lib.rtmi_debug_form_factor_kernel(rad.handle) == 1        # measured on that call's first rows: in a room the path walk wins
+    # the CRCs bench.py prints for these rows of the matrix it times (formfactor.crc32_of_pinned_rows) are the oracle's,
+    # committed by oracle/gen_golden_c5_rows.py: bench line and suite cannot drift apart
+    import json, os, zlib
+    from conftest import GOLDEN
+    pin = json.load(open(os.path.join(GOLDEN, "c5_box_rows.json")))
+    assert pin["patches"] == n and sorted(int(k) for k in pin["crc32"]) == C5_BOX_ROWS
+    for r in C5_BOX_ROWS:
+        got = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=r // 4096 * 4096, n_rows=min(4096, n + 1 - r // 4096 * 4096)).cpu().numpy()[r % 4096]
+        assert "%08x" % zlib.crc32(got[: n + 1].tobytes()) == pin["crc32"][str(r)], "row %d" % r
+    scene.check()
+
+
+def test_c5_whole_64k_matrix_path_walk_equals_root_traversal(rt, monkeypatch):
+    """Every one of the 64 744 x 64 745 entries bench.py times: the path walk (plane flags, certain-hit shortcut, per-pair
+    beam) against the root-traversal kernel that tests every ray from the root — compared on the device block by block
+    (4096 rows, 1 GB each), bit for bit.  ≈ 0.6 s + 4 s of GPU time."""
+    import torch
+    from raytracer_amd import workloads
+    verts, normals, light = workloads.closed_box(74, hole=0.3)
+    n = len(verts)
+    scene = rt.Scene(verts)
+    rad = rt.Radiosity(scene, normals, light)
+    ld = (n + 1 + 3) // 4 * 4
+    A = torch.empty((4096, ld), dtype=torch.float32, device="cuda")
+    Bf = torch.empty((4096, ld), dtype=torch.float32, device="cuda")
+    lc = np.ascontiguousarray(light, np.float64)
+    st = torch.cuda.current_stream().cuda_stream
+    differing, nonzero = 0, 0
+    for first in range(0, n + 1, 4096):
+        cnt = min(4096, n + 1 - first)
+        for kernel, out in (("path", A), ("flat", Bf)):
+            monkeypatch.setenv("RTMI_FF_KERNEL", kernel)
+            rc = rt.lib.rtmi_form_factors_dev(rad.handle, lc.ctypes.data, 10, 30, 1, 0, first, cnt, out.data_ptr(), ld, st)
+            assert rc == 0, rt.lib.rtmi_last_error().decode()
+        torch.cuda.synchronize()
+        differing += int((A[:cnt, : n + 1].view(torch.int32) != Bf[:cnt, : n + 1].view(torch.int32)).sum())
+        nonzero += int((A[:cnt, :n] > 0).sum())
+        assert differing == 0, "rows %d..%d" % (first, first + cnt)
+    monkeypatch.delenv("RTMI_FF_KERNEL", raising=False)
+    assert rt.lib.rtmi_debug_form_factor_planes(rad.handle) == 1
+    assert 0.7 < nonzero / float(n) ** 2 < 0.85                  # pairs on different walls see each other (5/6 of all, less the opening)
     scene.check()
 
 

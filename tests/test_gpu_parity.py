@@ -753,12 +753,19 @@ def test_sharded_solve_inside_the_library_one_rank(rt, monkeypatch):
         B, s1 = multi.solve_sharded_library(dF.data_ptr(), ld, n, 0, n, rho, dE, tol_rel=tol, max_sweeps=sweeps_max, check_every=ce)
         torch.cuda.synchronize()
         assert s0.sweeps == s1.sweeps and np.array_equal(B.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
-        assert s1.max_change == s0.max_change and abs(s1.rel_change - s0.rel_change) <= 1e-12 * max(s0.rel_change, 1e-300)
+        if tol > 0:      # (tolerance 0 = a fixed number of sweeps: the norms are never read back)
+            assert s1.max_change == s0.max_change and abs(s1.rel_change - s0.rel_change) <= 1e-12 * max(s0.rel_change, 1e-300)
+            assert s1.accelerated_sweeps == s0.accelerated_sweeps > 0 and s1.spectral_radius == s0.spectral_radius
+        else:
+            assert np.isnan(s0.rel_change) and np.isnan(s1.rel_change) and s1.accelerated_sweeps == 0
     # the Python loop over the same sweep (a group of one): the callback path on hardware
     def sweep(B_old, B_new, norms):
         rt.jacobi_sweep_dev(dF.data_ptr(), ld, n, 0, n, rho, dE.data_ptr(), B_old.data_ptr(), B_new.data_ptr(), norms.data_ptr(), st)
-    r = multi.solve_sharded(sweep, dE, n, tol_rel=1e-6, max_sweeps=500, check_every=3)
-    assert r.sweeps == s1.sweeps and np.array_equal(r.B.cpu().numpy(), B.cpu().numpy())
+    r = multi.solve_sharded(sweep, dE, n, tol_rel=1e-6, max_sweeps=500, check_every=3)      # (plain Jacobi)
+    monkeypatch.setenv("RTMI_SOLVER", "jacobi")
+    Bj, sj = multi.solve_sharded_library(dF.data_ptr(), ld, n, 0, n, rho, dE, tol_rel=1e-6, max_sweeps=500, check_every=3)
+    monkeypatch.delenv("RTMI_SOLVER")
+    assert r.sweeps == sj.sweeps > s1.sweeps and np.array_equal(r.B.cpu().numpy(), Bj.cpu().numpy())
     # a row range that is not the rank's block is refused when there is more than one rank; with one rank any range runs
     B2, s2 = multi.solve_sharded_library(dF.data_ptr(), ld, n, 0, 100, rho, dE, tol_rel=0.0, max_sweeps=2, check_every=1)
     assert s2.sweeps == 2
