@@ -91,8 +91,9 @@ int rtmi_scene_get_info(const rtmi_scene *, rtmi_scene_info *out);
  * ray instead of hanging the GPU, and raises the scene's error word; its launch leaves records unwritten.  Every later
  * entry point on the scene then fails with that message (sticky, like a device fault); rtmi_scene_check asks directly —
  * call it after synchronising the streams whose results you are about to trust.  No reference counterpart (the
- * reference's recursion cannot loop).  Launches of one scene may overlap on any number of streams (up to 256 different
- * streams per scene): each stream has its own work-queue counter. */
+ * reference's recursion cannot loop).  Launches of one scene may overlap on any number of streams: each stream handle that
+ * has launched on the scene keeps its own 4-byte work-queue counter for the scene's life (counters come in blocks of 256; the
+ * first launch on the 257th, 513th, ... distinct handle allocates a block — make it outside a graph capture). */
 int rtmi_scene_check(const rtmi_scene *);
 
 /* ---- closest hit --------------------------------------------------------------------------------

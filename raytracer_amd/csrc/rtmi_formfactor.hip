@@ -832,11 +832,17 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 	// (up to 1024 of them; they are written more than once, same bits), HIP events time them, the faster stays (that one call waits for the events).
 	// RTMI_FF_KERNEL=path|flat forces one.
 	auto launch_flat = [&](uint32_t first, uint32_t count, float *out) -> int {
-		const uint64_t total = (uint64_t)count * P->n, grid = (total + kBlock - 1) / kBlock;
-		if (grid > 0x7fffffffull) return fail(std::string(who) + ": too many entries for one launch; shard the rows");
-		hipLaunchKernelGGL(k_form_factors_flat, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes_binary, st, s->dev, pdev(P), samples, seed, first,
-		                   count, out, ld);
-		return launch_check(who);
+		// one lane per entry; a call with more entries than one grid holds goes out in row chunks (same stream, same bits)
+		const uint32_t rows_max = (uint32_t)std::min<uint64_t>(0xffffffffull, std::max<uint64_t>(1, (0x7fffffffull * kBlock) / std::max(1u, P->n)));
+		for (uint32_t done = 0; done < count;) {
+			const uint32_t rows = std::min(rows_max, count - done);
+			const uint64_t total = (uint64_t)rows * P->n, grid = (total + kBlock - 1) / kBlock;
+			hipLaunchKernelGGL(k_form_factors_flat, dim3((uint32_t)grid), dim3(kBlock), s->stack_bytes_binary, st, s->dev, pdev(P), samples, seed, first + done,
+			                   rows, out + (uint64_t)done * ld, ld);
+			if (launch_check(who)) return -1;
+			done += rows;
+		}
+		return 0;
 	};
 	auto launch_path = [&](uint32_t first, uint32_t count, float *out) -> int {
 		uint32_t band = std::max(1u, env_uint("RTMI_FF_BAND", 64));
@@ -879,14 +885,18 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		const bool capturing = hipStreamIsCapturing(st, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone;
 		if (kernel == 0 && !capturing && P->n >= 1024 && rows_p >= 256) {
 			const uint32_t cal = std::min(rows_p, 1024u);
+			// (the root traversal has one lane per entry and workgroups of even length: a quarter of the rows times it as
+			// well, and it is the slower kernel wherever the path walk serves at all — 66 ms of this call's 120 on the 64 K box)
+			const uint32_t cal_flat = std::max(256u, cal / 4u);
 			hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 			bool ok = hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess && hipEventCreate(&ev[2]) == hipSuccess;
 			float t_path = 0.f, t_flat = 0.f;
 			// (an untimed run first: after idle time the first long kernel runs at clocks that are still ramping up)
 			ok = ok && launch_path(row0, cal, d_F) == 0;
 			ok = ok && hipEventRecord(ev[0], st) == hipSuccess && launch_path(row0, cal, d_F) == 0 && hipEventRecord(ev[1], st) == hipSuccess &&
-			     launch_flat(row0, cal, d_F) == 0 && hipEventRecord(ev[2], st) == hipSuccess && hipEventSynchronize(ev[2]) == hipSuccess &&
+			     launch_flat(row0, cal_flat, d_F) == 0 && hipEventRecord(ev[2], st) == hipSuccess && hipEventSynchronize(ev[2]) == hipSuccess &&
 			     hipEventElapsedTime(&t_path, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&t_flat, ev[1], ev[2]) == hipSuccess;
+			t_flat *= (float)cal / (float)cal_flat;
 			for (hipEvent_t e : ev)
 				if (e) (void)hipEventDestroy(e);
 			if (!ok) return fail(std::string(who) + ": timing the two form-factor kernels failed: " + hipGetErrorString(hipGetLastError()));

@@ -4,6 +4,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "bvh_build.hpp"
 #include "rtmi_device.hpp"
@@ -20,6 +21,8 @@ struct rtmi_scene {
 	                                  // before each kernel); launches on different streams never share one — no in-flight limit.
 	std::mutex queue_mutex;
 	std::unordered_map<void *, uint32_t> stream_slot;
+	std::vector<int *> queue_more;    // further blocks of kQueueSlots counters, added when a host has launched on more distinct streams than
+	                                  // the blocks so far hold (a server that makes a stream per request): slot k lives in block k / kQueueSlots
 	std::unordered_map<const void *, int> blocks_per_cu; // hipOccupancyMaxActiveBlocksPerMultiprocessor per (kernel) at stack_bytes of LDS
 	void *h_small = nullptr, *d_small = nullptr; // host-mapped staging of the host-pointer entries' small batches (lazily made)
 	std::mutex small_mutex;

@@ -584,22 +584,33 @@ int launch_check(const char *who) {
 
 // The queue counter of a launch: one per STREAM (launches on a stream are ordered, so they share it; it is zeroed on the
 // stream just before the kernel).  Launches on different streams never share a counter, however many are in flight.
+// A counter is never taken away from a stream handle while the scene lives (nothing says when a stream's last launch on
+// it has drained, or that the handle is dead): a host that keeps making new streams gets further blocks of counters —
+// 4 bytes per distinct handle value; the allocator reuses the values of destroyed streams, which land on their old slot.
+// The first launch on the 257th, 513th, ... distinct stream therefore allocates (hipMalloc: not inside a graph capture).
+constexpr uint32_t kQueueSlotsMax = 1u << 22;
 int *queue_slot(rtmi_scene *s, hipStream_t st, const char *who) {
-	uint32_t idx;
+	int *slot = nullptr;
 	{
 		std::lock_guard<std::mutex> lock(s->queue_mutex);
+		uint32_t idx;
 		auto it = s->stream_slot.find((void *)st);
 		if (it != s->stream_slot.end()) idx = it->second;
 		else {
-			if (s->stream_slot.size() >= kQueueSlots) {
-				fail(std::string(who) + ": more than " + std::to_string(kQueueSlots) + " different streams have launched on this scene");
+			idx = (uint32_t)s->stream_slot.size();
+			if (idx >= kQueueSlotsMax) {
+				fail(std::string(who) + ": more than " + std::to_string(kQueueSlotsMax) + " different streams have launched on this scene");
 				return nullptr;
 			}
-			idx = (uint32_t)s->stream_slot.size();
+			if (idx >= kQueueSlots * (1u + (uint32_t)s->queue_more.size())) {
+				int *block = nullptr;
+				if (hipMalloc(&block, kQueueSlots * sizeof(int)) != hipSuccess) { fail(std::string(who) + ": hipMalloc of a block of queue counters failed"); return nullptr; }
+				try { s->queue_more.push_back(block); } catch (const std::exception &) { (void)hipFree(block); fail(std::string(who) + ": out of memory"); return nullptr; }
+			}
 			s->stream_slot.emplace((void *)st, idx);
 		}
+		slot = (idx < kQueueSlots ? s->d_queue : s->queue_more[idx / kQueueSlots - 1]) + idx % kQueueSlots;
 	}
-	int *slot = s->d_queue + idx;
 	if (hipMemsetAsync(slot, 0, sizeof(int), st) != hipSuccess) { fail(std::string(who) + ": hipMemsetAsync failed"); return nullptr; }
 	return slot;
 }
@@ -805,6 +816,7 @@ void rtmi_scene_destroy(rtmi_scene *s) {
 	if (s->dev.tris) (void)hipFree((void *)s->dev.tris);
 	if (s->d_v1_orig) (void)hipFree(s->d_v1_orig);
 	if (s->d_queue) (void)hipFree(s->d_queue);
+	for (int *b : s->queue_more) (void)hipFree(b);
 	if (s->h_error) (void)hipHostFree(s->h_error);
 	if (s->h_small) (void)hipHostFree(s->h_small); // the small-batch buffer of the host-pointer calls (trace_host)
 	delete s;

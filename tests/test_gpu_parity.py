@@ -688,6 +688,42 @@ def test_many_launches_in_flight_on_two_streams(rt):
             assert np.array_equal(got["tri"], want["tri"]) and np.array_equal(got["t"], want["t"])
 
 
+def test_more_streams_than_one_block_of_queue_counters(rt):
+    """A long-lived scene used by a host that makes a stream per request: 600 distinct live streams launch
+    on one scene — more than the 256 counters of its first block; the scene adds blocks instead of failing, and every
+    launch writes the single-stream records."""
+    import torch
+    from raytracer_amd import workloads
+    tris = workloads.soup(5000, seed=8, edge=0.08)
+    scene = rt.Scene(tris)
+    cam = rt.Camera.from_cam14(workloads.SOUP_CAM14, (160, 100))
+    want = primary_frame(rt, scene, cam)
+    n = cam.x_res * cam.y_res
+    streams = [torch.cuda.Stream() for _ in range(600)]       # (torch hands out pooled handles: only the distinct ones count)
+    distinct = len({s.cuda_stream for s in streams})
+    hip = rt.api.C.CDLL("libamdhip64.so")
+    raw = []
+    for _ in range(max(0, 600 - distinct)):                    # top up with raw HIP streams so that > 256 distinct handles are live at once
+        h = rt.api.C.c_void_p()
+        assert hip.hipStreamCreate(rt.api.C.byref(h)) == 0
+        raw.append(h)
+    handles = sorted({s.cuda_stream for s in streams} | {h.value for h in raw})
+    assert len(handles) > 256
+    outs = [torch.zeros(n * rt.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(8)]
+    torch.cuda.synchronize()
+    for k, h in enumerate(handles):
+        scene.primary_dev(cam, outs[k % 8].data_ptr(), tile=(64, 64), stream=h)
+        if k % 8 == 7:
+            torch.cuda.synchronize()                           # (8 launches in flight at a time, each into its own buffer)
+    torch.cuda.synchronize()
+    scene.check()
+    for o in outs:
+        got = o.cpu().numpy().view(rt.HIT_DTYPE)
+        assert np.array_equal(got["tri"], want["tri"]) and np.array_equal(got["t"], want["t"])
+    for h in raw:
+        assert hip.hipStreamDestroy(h) == 0
+
+
 @pytest.mark.parametrize("n", [11, 257, 1000])
 def test_jacobi_sweep_vs_oracle_rgb(rt, oracle, n):
     import torch
