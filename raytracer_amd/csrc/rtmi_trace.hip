@@ -629,7 +629,11 @@ uint32_t persistent_grid_of(rtmi_scene *s, const void *kernel, uint64_t n_items)
 		}
 	}
 	const uint64_t full = (uint64_t)per_cu * (uint64_t)s->n_cus;
-	return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full, (n_items + kBlock - 1) / kBlock));
+	// RTMI_MIN_RAYS_PER_LANE (experiment, tools/quick_small_grid.py): a launch with fewer items per resident lane than this
+	// gets a smaller grid — fewer waves that live longer and refill more often, at a lower occupancy
+	const uint64_t min_rays = env_uint("RTMI_MIN_RAYS_PER_LANE", 0);
+	const uint64_t want = min_rays ? std::max<uint64_t>((uint64_t)s->n_cus, (n_items + kBlock * min_rays - 1) / (kBlock * min_rays)) : full;
+	return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(full, want), (n_items + kBlock - 1) / kBlock));
 }
 template <class K>
 static uint32_t persistent_grid(rtmi_scene *s, K kernel, uint64_t n_items) {
