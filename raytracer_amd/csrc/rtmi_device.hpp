@@ -60,6 +60,19 @@ constexpr uint32_t kQueueChunk = 256;     // items a wave takes from the launch'
 #endif
 constexpr uint32_t kTailChunk = RTMI_TAIL_CHUNK; // ... and once the queue is down to its last chunk per resident wave (see trace_queue)
 constexpr int kLeaf = INT32_MIN + 1;      // lane state: working through the triangles of a leaf
+#ifndef RTMI_SPLIT
+#define RTMI_SPLIT 0
+#endif
+#ifndef RTMI_POOL
+#define RTMI_POOL 1
+#endif
+constexpr uint32_t kPoolTake = 64;        // items a wave moves from the shared range into its own at a time
+constexpr bool kPool = RTMI_POOL != 0;    // the waves of a workgroup share what they claim from the launch's queue (trace_queue)
+constexpr bool kSplit = RTMI_SPLIT != 0;  // closest-hit queues: once a wave has no items left, its idle lanes take subtrees off the busy lanes' stacks (trace_queue)
+#ifndef RTMI_SPLIT_PAIRS
+#define RTMI_SPLIT_PAIRS 16
+#endif
+constexpr int kSplitPairs = RTMI_SPLIT_PAIRS; // subtrees handed over per scheduling round, at most
 #ifndef RTMI_TOP_LDS
 #define RTMI_TOP_LDS 0
 #endif
@@ -302,6 +315,30 @@ __device__ __forceinline__ uint32_t wave_slots() { // 64 on the first active lan
 	return (uint32_t)(__ffsll((long long)m) - 1) == (threadIdx.x & 63u) ? 64u : 0u;
 }
 
+__device__ __forceinline__ double readlane_f64(double x, int k) { // k wave-uniform
+	const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, k), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), k);
+	return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__device__ __forceinline__ double shfl_f64(double x, uint32_t src) { // every lane of the wave must be active
+	const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+	const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)b, (int)src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(b >> 32), (int)src, 64);
+	return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// position of the n-th set bit of m (n < popcount(m)); m wave-uniform, n per lane
+__device__ __forceinline__ uint32_t nth_set_bit64(unsigned long long m, uint32_t n) {
+	uint32_t w = (uint32_t)m, base = 0;
+	const uint32_t c = (uint32_t)__popc(w);
+	if (n >= c) { n -= c; w = (uint32_t)(m >> 32); base = 32; }
+#pragma unroll
+	for (uint32_t s = 16; s >= 1; s >>= 1) {
+		const uint32_t c2 = (uint32_t)__popc(w & ((1u << s) - 1u));
+		if (n >= c2) { n -= c2; w >>= s; base += s; }
+	}
+	return base;
+}
+
 struct HitP { double t; uint32_t pos; }; // pos: index into the leaf-ordered triangle array, RTMI_MISS = no hit (t = 0)
 
 template <bool WIDE> struct StepRay;
@@ -374,7 +411,7 @@ __device__ __forceinline__ void trace(const SceneDev &S, double ox, double oy, d
 
 // ---------------------------------------------------------------- persistent waves over a work queue
 // refill threshold and phase-vote weights of trace_queue (RTMI_REFILL / RTMI_VOTE_NODE / RTMI_VOTE_LEAF override)
-struct Tune { int thresh, vote_node, vote_leaf; uint32_t chunk, tail_chunk; }; // chunk: items per claim (kQueueChunk unless the launch is small)
+struct Tune { int thresh, vote_node, vote_leaf; uint32_t chunk, tail_chunk, max_chunk; }; // chunk: items per claim (kQueueChunk unless the launch is small)
 
 // The launch owns `n_items` work items (rays) and ONE counter in device memory (zeroed on the stream before the
 // kernel); its grid is persistent — as many workgroups as the device holds at once.  Every lane traces one ray at
@@ -408,6 +445,17 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 	const WNode *top = nullptr;
 	const uint32_t n_top = 0;
 #endif
+	__shared__ unsigned long long pool_word;
+	__shared__ uint32_t pool_seen_word;
+	unsigned long long *pool = &pool_word;
+	__shared__ uint32_t pool_sum_word;        // items the workgroup claimed after its first claim
+	__shared__ unsigned long long pool_t_word; // when it first claimed from the launch's counter (wall_clock64, 100 MHz)
+	volatile uint32_t *pool_seen = &pool_seen_word, *pool_sum = &pool_sum_word;
+	volatile unsigned long long *pool_t = &pool_t_word;
+	if (kPool) {
+		if (threadIdx.x == 0) { pool_word = 0ull; pool_seen_word = 0u; pool_sum_word = 0u; pool_t_word = 0ull; }
+		__syncthreads();
+	}
 	RayD R = {0, 0, 0, 0, 0, 1, 0};
 	RayW r = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	HitQ h = {0.0, 0.f, 0.f, RTMI_MISS};
@@ -419,23 +467,31 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 	bool more = true;  // items are left for this wave: in its own range or in the launch's queue (wave-uniform)
 	bool global_more = true;
 	uint32_t w_next = 0, w_end = 0; // the wave's own range of claimed items (wave-uniform)
-	// When the queue runs dry every wave still holds what is left of its last claim, so a launch ends with a tail of about one
-	// chunk's worth of rays per lane (4 rays of ≈ 90 µs on the C3 soup: 12 % of the 4K frame, half of a million-ray launch).
-	// Once fewer items are left than one full chunk per resident wave, claims are therefore smaller (the wave judges that from
-	// the counter value its previous claim returned); all other claims stay large to keep the atomics on the counter rare.
-	// The claim size adapts to what the rays cost (wave-uniform): claims are atomics on ONE counter, which serialise at about
-	// 8 ns each, so a wave should not claim more often than every few dozen rounds — cheap rays (a room's primary rays,
-	// short any-hit rays) keep large claims; a wave that went more than 128 rounds on one claim halves its next one (down to
-	// 64 items, one 8 x 8 pixel square), one that came back within 40 doubles it again.  Measured (MI355X, round 2): C3
-	// 2.84 ms with fixed 256-item claims, 2.57 ms with fixed 64 — but fixed 64 makes the room's primary rays 0.52 ms instead
-	// of 0.31 (32 K atomics); this rule: C3 2.72-2.75 ms, room 0.30 ms.  Guided self-scheduling (claim <= 1/2 or 1/4 of an
-	// even share of what is left, floor 32) was measured too: C3 2.65-2.69 ms, but every cheap launch 8-30 % slower (its end
-	// game is all small claims); not kept.
-	uint32_t cur_chunk = tune.chunk, since_claim = 0;
+	// Claims from the launch's counter, their size and what a launch's end looks like: see the refill below.  History of the
+	// sizing (MI355X): fixed 256-item claims per wave, C3 2.84 ms; fixed 64, 2.57 ms but the room's 2 M primary rays 0.52 instead
+	// of 0.31 ms (32 K atomics); round 2's rule (halve after 128 scheduling rounds on one claim, double within 40, between 64 and
+	// 256): C3 2.69-2.75 ms, room 0.30 ms, 33 M short any-hit rays 1.63 ms of which 1.04 ms were the 130 K atomics; round 3 (sizes
+	// from the measured rate, shared range per workgroup): C3 2.52 ms, those any-hit rays 1.30 ms, the test1 frame 0.235 instead
+	// of 0.285 ms (profiles/ab_r03.md).
 	const uint32_t resident_waves = gridDim.x * (kBlock / 64u);
 	uint32_t seen = 0; // the counter as of this wave's last claim
+	uint64_t t_first = 0;     // when this wave first claimed (wall_clock64, 100 MHz) ...
+	uint32_t sum_claimed = 0; // ... and the items it has claimed since (without that first claim, which went out at once)
 	uint32_t guard = 0;
+	// End of the launch (closest hit only): a wave whose queue has run dry spreads the rays it still holds over its idle lanes.
+	// A busy lane gives away the BOTTOM entry of its stack (the subtree it would reach last: the far side of a split near the
+	// root) to an idle lane, which walks it with a copy of the ray and of the best hit so far; the entry is replaced by
+	// kSentinel, which the giver pops last of all and which ends its walk like an empty stack does.  A helper that finishes is
+	// folded into the lane that owns the item (smaller t wins, equal t -> smaller original id: the rule of the triangle step, so
+	// the record is the sequential one whatever the split) and is free again; the owner writes the record when it and all its
+	// helpers are done.  Helpers do not see hits found after they left, so they may visit subtrees the sequential walk would
+	// have culled — on lanes that had nothing to do.
+	constexpr bool SPLIT = kSplit && !ANY;
+	int sb = 0;            // stack entries [0, sb) of this lane were given away
+	uint32_t owner = lane; // the lane that holds the item this lane works for
+	int nhelp = 0;         // helpers at work for this lane's item
 	auto start = [&]() { // R holds a new ray: reset the lane's traversal state
+		sb = 0; owner = lane; nhelp = 0;
 		h.u = h.v = 0.f; h.pos = RTMI_MISS;
 		best = R.tmax;
 		tbest = f32_above(best);
@@ -447,10 +503,86 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 		// Retire + refill together, and only when enough lanes wait for it (or nothing else is left to do):
 		// emit/fetch can be long (form factors: sample points, cosines, a division), so they must not run
 		// for one lane at a time.
-		const bool fin = have && cur == kSentinel;
+		if (SPLIT && !more) {
+			// helpers that are done: fold their hit into the owner's, free the lane
+			unsigned long long hf = __ballot(have && owner != lane && cur == kSentinel);
+			while (hf != 0ull) {
+				const int k = __ffsll((long long)hf) - 1;
+				hf &= hf - 1ull;
+				const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)owner, k);
+				const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)h.pos, k);
+				const double tk_ = readlane_f64(best, k);
+				const float uk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.u), k));
+				const float vk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.v), k));
+				if (lane == o) {
+					--nhelp;
+					if (pk != RTMI_MISS && pk != h.pos &&
+					    (tk_ < best || (tk_ == best && h.pos != RTMI_MISS && S.tris[pk].orig < S.tris[h.pos].orig))) {
+						best = tk_;
+						tbest = f32_above(best);
+						h.u = uk; h.v = vk; h.pos = pk;
+					}
+				}
+				if (lane == (uint32_t)k) { have = false; owner = lane; }
+			}
+			// helpers at work take over the owner's best hit when it is nearer than theirs (the owner walks the near side: what it
+			// finds culls most of what the helpers were given)
+			if (__ballot(have && owner != lane) != 0ull) {
+				const double ob = shfl_f64(best, owner);
+				const uint32_t op = (uint32_t)__shfl((int)h.pos, (int)owner, 64);
+				if (have && owner != lane && ob < best) {
+					best = ob;
+					tbest = f32_above(best);
+					h.pos = op; // u, v stay stale: a record copied from the owner never travels back (the fold skips equal positions)
+				}
+			}
+			// idle lanes take subtrees from busy ones: the k-th idle lane from the k-th lane that has something to give
+			const unsigned long long idle = __ballot(!have);
+			const bool can_give = have && cur != kSentinel && sp > sb;
+			const unsigned long long don = __ballot(can_give);
+			if (idle != 0ull && don != 0ull) {
+				const uint32_t n_pairs = min((uint32_t)__popcll(idle), (uint32_t)__popcll(don));
+				const uint32_t rank_i = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+				const uint32_t rank_d = __builtin_amdgcn_mbcnt_hi((uint32_t)(don >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)don, 0u));
+				int e = 0;
+				if (can_give && rank_d < n_pairs) {
+					e = stack[sb * kBlock];
+					stack[sb * kBlock] = kSentinel;
+					++sb;
+				}
+				const bool take = !have && rank_i < n_pairs;
+				const int src = take ? (int)nth_set_bit64(don, rank_i) : (int)lane;
+				const int pe = __shfl(e, src, 64);
+				const uint32_t po = (uint32_t)__shfl((int)owner, src, 64);
+				const uint32_t pp = (uint32_t)__shfl((int)h.pos, src, 64);
+				const float pu = __shfl(h.u, src, 64), pv = __shfl(h.v, src, 64);
+				const double pb = shfl_f64(best, src);
+				const double rdx = shfl_f64(R.dx, src), rdy = shfl_f64(R.dy, src), rdz = shfl_f64(R.dz, src), rtm = shfl_f64(R.tmax, src);
+				double rox = 0.0, roy = 0.0, roz = 0.0;
+				if (!UNIFORM_O) { rox = shfl_f64(R.ox, src); roy = shfl_f64(R.oy, src); roz = shfl_f64(R.oz, src); }
+				if (take) {
+					R.dx = rdx; R.dy = rdy; R.dz = rdz; R.tmax = rtm;
+					if (!UNIFORM_O) { R.ox = rox; R.oy = roy; R.oz = roz; }
+					start();
+					have = true;
+					owner = po;
+					best = pb;
+					tbest = f32_above(best);
+					h.u = pu; h.v = pv; h.pos = pp;
+					cur = pe;
+				}
+				unsigned long long nh = __ballot(take); // the owners count their new helpers
+				while (nh != 0ull) {
+					const int k = __ffsll((long long)nh) - 1;
+					nh &= nh - 1ull;
+					if (lane == (uint32_t)__builtin_amdgcn_readlane((int)owner, k)) ++nhelp;
+				}
+			}
+		}
+		const bool fin = have && cur == kSentinel && (!SPLIT || (owner == lane && nhelp == 0));
 		const int n_fin = __popcll(__ballot(fin)), n_free = more ? __popcll(__ballot(!have)) : 0;
 		const int n_busy = __popcll(__ballot(have && cur != kSentinel));
-		if (n_fin + n_free >= thresh || (n_busy == 0 && n_fin + n_free > 0)) {
+		if (n_fin + n_free >= thresh || (n_busy == 0 && n_fin + n_free > 0) || (SPLIT && !more && n_fin > 0)) {
 			if (fin) {
 				h.t = h.pos != RTMI_MISS ? best : 0.0;
 				if (emit(item, h, R)) start(); // the item wants another ray (R refilled): same lane carries on
@@ -467,14 +599,127 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 					const uint32_t left = w_end - w_next;
 					uint32_t fresh = 0, fresh_end = 0;
 					bool got = false;
+					bool pool_left = false;
+					if (kPool) {
+						// What a wave claims from the launch's counter goes into a range the workgroup's waves share (one 64-bit word in
+						// LDS: next | end << 32, taken from by compare-and-swap).  A wave takes kPoolTake = 64 consecutive items from it at
+						// a time into its own range [w_next, w_end) and refills its lanes from there (one 8 x 8 square of primary rays,
+						// the rays of neighbouring hit points: a wave's lanes stay on neighbouring rays; refills straight from the shared
+						// range, 16 items here and 16 there, were measured 8 % slower on the fused soft-shadow and AO queues).  When the
+						// queue runs dry a workgroup is left with at most one claim for its 256 lanes and a wave with less than one ray
+						// per lane — not with one claim per wave.
+						if (left < nidle) {
+							const uint32_t leader = (uint32_t)(__ffsll((long long)idle) - 1);
+							const uint32_t need = nidle - left;
+							uint32_t g_base = 0, g_n = 0, flags = 0, seen_now = seen; // flags: 1 = queue dry, 2 = pool not empty afterwards
+							// Claim size (pool form).  A claim is an atomic on ONE address: about 8 ns each, one after the other, for the
+							// whole device.  A workgroup knows the rate at which it uses items (what it claimed since its first claim over
+							// the time since then, 100 MHz clock) and sizes its claims so that all resident workgroups claiming at its pace
+							// keep the counter busy a quarter of the time at most: the power of two nearest to rate x gridDim.x x 32 ns,
+							// between 64 and max_chunk.  (Doubling / halving on the last interval alone wandered up to the cap: measured.)
+							// That lands cheap rays (short any-hit rays: 33 M in a millisecond) on 1024-item claims and the soup's primary
+							// rays on 128.  Towards the end of the queue the size follows what is left: half an even share per workgroup,
+							// but not below a quarter of the paced size (the last claims may crowd the counter, briefly).
+							if (lane == leader) {
+								for (;;) {
+									const unsigned long long v = __hip_atomic_load(pool, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+									const uint32_t nx = (uint32_t)v, en = (uint32_t)(v >> 32);
+									if (nx < en) {
+										const uint32_t m = min(max(need, kPoolTake), en - nx);
+										if (atomicCAS(pool, v, (unsigned long long)(nx + m) | ((unsigned long long)en << 32)) != v) continue;
+										g_base = nx; g_n = m;
+										if (nx + m < en) flags |= 2u;
+										break;
+									}
+									if (!global_more) break;
+									if (*pool_seen >= n_items) { flags |= 1u; break; } // another wave of the workgroup found the queue dry
+									const uint64_t now = wall_clock64();
+									const uint64_t t0 = *pool_t;   // the workgroup's first claim (its items went out at once: they fill the lanes)
+									const uint32_t sum = *pool_sum; // items claimed after that one and used up by now
+									uint32_t cc = tune.chunk;
+									if (t0 != 0ull && sum != 0u) {
+										const uint64_t dt = now > t0 ? now - t0 : 1ull;
+										const uint64_t want = (uint64_t)sum * gridDim.x * 16ull / (dt * 5ull); // items used per tick x (gridDim.x x 3.2 ticks)
+										const uint32_t w = (uint32_t)min((unsigned long long)tune.max_chunk, max(64ull, (unsigned long long)(want + (want >> 1))));
+										cc = 1u << (31 - __clz((int)w)); // the power of two nearest to `want`
+									}
+									const uint32_t seen_wg = *pool_seen;
+									const uint32_t rem = seen_wg < n_items ? n_items - seen_wg : 0u;
+									const uint32_t chunk = min(cc, max(max(32u, cc >> 2), rem / (2u * gridDim.x)));
+									const uint32_t base = (uint32_t)atomicAdd(counter, (int)chunk);
+									seen_now = base;
+									*pool_seen = base; // the other waves of the workgroup learn how far the queue has got
+									if (t0 == 0ull) *pool_t = now;
+									else *pool_sum = sum + chunk;
+									flags |= 4u; // claimed from the launch's counter
+									if (base >= n_items) { flags |= 1u; break; }
+									const uint32_t cend = base + chunk < n_items ? base + chunk : n_items;
+									const uint32_t m = min(max(need, kPoolTake), cend - base);
+									g_base = base; g_n = m;
+									if (base + m < cend) {
+										if (atomicCAS(pool, v, (unsigned long long)(base + m) | ((unsigned long long)cend << 32)) == v) flags |= 2u;
+										else g_n = cend - base; // somebody else published first: the whole claim stays with this wave
+									}
+									break;
+								}
+							}
+							fresh = (uint32_t)__builtin_amdgcn_readlane((int)g_base, (int)leader);
+							fresh_end = fresh + (uint32_t)__builtin_amdgcn_readlane((int)g_n, (int)leader);
+							flags = (uint32_t)__builtin_amdgcn_readlane((int)flags, (int)leader);
+							seen = (uint32_t)__builtin_amdgcn_readlane((int)seen_now, (int)leader);
+							got = fresh_end > fresh;
+							if (flags & 1u) global_more = false;
+							pool_left = (flags & 2u) != 0u;
+							if (!have) {
+								const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+								uint32_t idx = 0;
+								bool ok = false;
+								if (below < left) { idx = w_next + below; ok = true; }
+								else if (got) { idx = fresh + (below - left); ok = idx < fresh_end; }
+								if (ok && fetch(idx, R)) {
+									item = idx;
+									have = true;
+									start();
+								}
+							}
+							w_next = fresh + need < fresh_end ? fresh + need : fresh_end; // the rest of the piece is this wave's own
+							w_end = fresh_end;
+						} else {
+							if (!have) {
+								const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+								if (fetch(w_next + below, R)) {
+									item = w_next + below;
+									have = true;
+									start();
+								}
+							}
+							w_next += nidle;
+							pool_left = true; // not looked at: assume so
+						}
+						more = global_more || w_next < w_end || pool_left;
+					} else {
 					if (left < nidle && global_more) {
 						const uint32_t leader = (uint32_t)(__ffsll((long long)idle) - 1);
 						uint32_t base = 0;
-						if (since_claim > 128u && cur_chunk > 64u) cur_chunk >>= 1;
-						else if (since_claim < 40u && cur_chunk < tune.chunk) cur_chunk <<= 1;
-						since_claim = 0;
-						// once fewer items are left than one claim per resident wave, claims are halved (see above)
-						const uint32_t chunk = (seen < n_items && n_items - seen > resident_waves * cur_chunk) ? cur_chunk : max(tune.tail_chunk, cur_chunk >> 1);
+						// Claim size.  A claim is an atomic on ONE address: about 8 ns each, one after the other, for the whole device
+						// (33 M short any-hit rays in 256-item claims: 130 K atomics = 1.04 ms of a 1.6 ms launch).  A wave knows the rate
+						// at which it uses items (what it claimed since its first claim over the time since then, 100 MHz clock) and sizes
+						// its claims so that all resident waves claiming at its pace keep the counter busy a quarter of the time at most:
+						// the power of two nearest to rate x resident_waves x 32 ns, between 64 (one 8 x 8 square) and max_chunk.  Towards
+						// the end of the queue the size follows what is left — half an even share per wave — but not below a quarter of
+						// the paced size (the last claims may crowd the counter, briefly).
+						const uint64_t now = wall_clock64();
+						uint32_t cc = tune.chunk;
+						if (t_first != 0ull && sum_claimed != 0u) {
+							const uint64_t dt = now > t_first ? now - t_first : 1ull;
+							const uint64_t want = (uint64_t)sum_claimed * resident_waves * 16ull / (dt * 5ull); // items per tick x (resident_waves x 3.2 ticks)
+							const uint32_t w = (uint32_t)min((unsigned long long)tune.max_chunk, max(64ull, (unsigned long long)(want + (want >> 1))));
+							cc = 1u << (31 - __clz((int)w));
+						}
+						const uint32_t rem = seen < n_items ? n_items - seen : 0u;
+						const uint32_t chunk = min(cc, max(max(tune.tail_chunk, cc >> 2), rem / (2u * resident_waves)));
+						if (t_first == 0ull) t_first = now;
+						else sum_claimed += chunk;
 						if (lane == leader) base = (uint32_t)atomicAdd(counter, (int)chunk);
 						fresh = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
 						seen = fresh;
@@ -506,6 +751,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 						w_next = w_end;
 					}
 					more = global_more || w_next < w_end;
+					}
 				}
 			}
 		}
@@ -516,7 +762,6 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 			cur = kLeaf;
 		}
 		if (++guard > S.guard) { give_up(S); break; } // a wave that cannot finish must still end: never reached on valid input
-		++since_claim;
 		// Vote: the wave runs ONE node step or ONE triangle step per iteration, whichever has more lanes
 		// waiting (a triangle step costs about twice a node step).  Lanes of the other kind simply wait, so
 		// no lane ever runs ahead speculatively and the visited set is exactly the sequential one.

@@ -343,6 +343,7 @@ Tune refill_threshold() { // the tuning environment is read once
 		x.vote_leaf = (int)env_uint("RTMI_VOTE_LEAF", 3);
 		x.chunk = kQueueChunk;
 		x.tail_chunk = kTailChunk;
+		x.max_chunk = std::max(64u, env_uint("RTMI_MAX_CHUNK", 512));
 		return x;
 	}();
 	return t;
@@ -354,7 +355,7 @@ Tune refill_threshold() { // the tuning environment is read once
 // of the end-game halving.
 Tune launch_tune(Tune t, uint32_t grid, uint64_t n_items) {
 	static const unsigned fixed = env_uint("RTMI_CHUNK", 0);
-	if (fixed) { t.chunk = fixed; t.tail_chunk = std::max(16u, fixed / 2u); return t; }
+	if (fixed) { t.chunk = fixed; t.tail_chunk = std::max(16u, fixed / 2u); t.max_chunk = fixed; return t; }
 	const uint64_t per_wave = n_items / std::max<uint64_t>(1, (uint64_t)grid * (kBlock / 64));
 	t.chunk = per_wave < kQueueChunk ? kQueueChunk / 2u : kQueueChunk;
 	t.tail_chunk = 32u;
