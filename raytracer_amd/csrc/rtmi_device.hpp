@@ -339,6 +339,10 @@ __device__ __forceinline__ uint32_t nth_set_bit64(unsigned long long m, uint32_t
 	return base;
 }
 
+#ifdef RTMI_TAIL_DIAG
+static __device__ unsigned long long g_tail_diag[5 * 8192]; // per wave of the last primary-ray launch (this translation unit's copy)
+#endif
+
 struct HitP { double t; uint32_t pos; }; // pos: index into the leaf-ordered triangle array, RTMI_MISS = no hit (t = 0)
 
 template <bool WIDE> struct StepRay;
@@ -478,6 +482,11 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 	uint64_t t_first = 0;     // when this wave first claimed (wall_clock64, 100 MHz) ...
 	uint32_t sum_claimed = 0; // ... and the items it has claimed since (without that first claim, which went out at once)
 	uint32_t guard = 0;
+#ifdef RTMI_TAIL_DIAG // diagnostic builds (tools/tail_diag.py): when each wave started, found its queue dry, and ended (100 MHz ticks)
+	const unsigned long long diag_t0 = wall_clock64();
+	unsigned long long diag_dry = 0;
+	uint32_t diag_rounds_after = 0, diag_busy_after = 0;
+#endif
 	// End of the launch (closest hit only): a wave whose queue has run dry spreads the rays it still holds over its idle lanes.
 	// A busy lane gives away the BOTTOM entry of its stack (the subtree it would reach last: the far side of a split near the
 	// root) to an idle lane, which walks it with a copy of the ray and of the best hit so far; the entry is replaced by
@@ -762,6 +771,13 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 			cur = kLeaf;
 		}
 		if (++guard > S.guard) { give_up(S); break; } // a wave that cannot finish must still end: never reached on valid input
+#ifdef RTMI_TAIL_DIAG
+		if (!more) {
+			if (diag_dry == 0) diag_dry = wall_clock64();
+			++diag_rounds_after;
+			diag_busy_after += (uint32_t)__popcll(__ballot(have && cur != kSentinel));
+		}
+#endif
 		// Vote: the wave runs ONE node step or ONE triangle step per iteration, whichever has more lanes
 		// waiting (a triangle step costs about twice a node step).  Lanes of the other kind simply wait, so
 		// no lane ever runs ahead speculatively and the visited set is exactly the sequential one.
@@ -814,6 +830,12 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 			}
 		}
 	}
+#ifdef RTMI_TAIL_DIAG
+	if (!ANY && UNIFORM_O && lane == 0) {
+		unsigned long long *o = g_tail_diag + 5u * ((blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6)) & 8191u);
+		o[0] = diag_t0; o[1] = diag_dry; o[2] = wall_clock64(); o[3] = diag_rounds_after; o[4] = diag_busy_after;
+	}
+#endif
 }
 
 // ---------------------------------------------------------------- reference vector helpers (double)

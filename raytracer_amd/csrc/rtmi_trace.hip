@@ -887,6 +887,11 @@ __global__ void k_debug_div3(const double *__restrict__ num3, const double *__re
 	shared3[3 * k] = q.x; shared3[3 * k + 1] = q.y; shared3[3 * k + 2] = q.z;
 	plain3[3 * k] = a.x / c; plain3[3 * k + 1] = a.y / c; plain3[3 * k + 2] = a.z / c;
 }
+#ifdef RTMI_TAIL_DIAG
+extern "C" int rtmi_debug_tail_read(unsigned long long *host_out) { // diagnostic builds only (tools/tail_diag.py); not in rtmi.h
+	return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rtmi::g_tail_diag), sizeof(unsigned long long) * 5 * 8192) == hipSuccess ? 0 : -1;
+}
+#endif
 int rtmi_debug_div3_dev(const double *d_num3, const double *d_den, uint64_t n, double *d_shared3, double *d_plain3, void *stream) {
 	const char *who = "rtmi_debug_div3_dev";
 	if (n == 0) return 0;
