@@ -452,6 +452,18 @@ int rtmi_radiosity_raster_dev(rtmi_patches *, const double *d_vertex_radiosity, 
                               uint8_t *d_pixels, void *stream);
 int rtmi_tone_map_radiosity_dev(const double *d_rgb, uint64_t n, uint8_t *d_pixels, void *stream);
 
+/* The first half of returnQuadTreeColor (Render2/radiosity_helper.h:156-213) for hosts without the reference's QuadTreeNode
+ * graph: the radiosity it attaches to each vertex of each element — over the elements a that share the vertex p with element e
+ * (QuadTreeNode::nextAdj), the mean of
+ *     (1 − |c_e − p| / full)·B_e + (1 − |p − c_a| / full)·B_a,   full = |c_e − p| + |p − c_a|,
+ * c = centerOfTriangle (:115-142: the crossing of two medians through calculatePseudoInverse), and B_e itself where nobody
+ * shares the vertex (:255-257).  The reference's own adjacency build is switched off (Render2/radiosity.cpp:167-199), so as
+ * shipped every vertex gets B_e (flat shading); the adjacency used here is "the same three doubles" — what an OBJ's shared
+ * vertex index gives — summed in element order.  Host code, host pointers: verts [n][9] (triVert1..3), B [n] (one channel),
+ * out [n][3] = what rtmi_radiosity_raster_dev / _trace_dev take as vertex radiosity.  Pinned against the compiled reference's
+ * own returnQuadTreeColor with nextAdj filled with that adjacency (tests/golden/g10_vertex_values.npz). */
+int rtmi_radiosity_vertex_values(const double *verts, uint32_t n, const double *B, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -237,6 +237,12 @@ class Oracle:
         self.lib.rto_radiosity_trace(C.c_long(len(verts)), _p(verts), _p(normals), _p(vr), C.c_long(len(o)), _p(o), _p(d), _p(rgb))
         return rgb
 
+    def vertex_values(self, verts, B):
+        verts = _f64(verts, (-1, 9)); B = _f64(B)
+        out = np.zeros((len(verts), 3))
+        self.lib.rto_vertex_values(C.c_long(len(verts)), _p(verts), _p(B), _p(out))
+        return out
+
     def pinv(self, verts):
         verts = _f64(verts, (-1, 9))
         A = np.zeros((len(verts), 3)); B = np.zeros((len(verts), 3)); ok = np.zeros(len(verts), np.uint8)
@@ -490,6 +496,10 @@ class Reference:
         rgb = np.zeros((len(o), 3))
         self.lib.ref_rad_trace_ray(h, C.c_long(len(o)), _p(o), _p(d), _p(rgb))
         return rgb
+
+    def rad_set_adjacency(self, h, ei, ej, pts):
+        ei, ej, pts = np.ascontiguousarray(ei, np.int32), np.ascontiguousarray(ej, np.int32), _f64(pts)
+        self.lib.ref_rad_set_adjacency(h, C.c_long(len(ei)), _p(ei), _p(ej), _p(pts))
 
     def rad_vertex_radiosity(self, h, n_el):
         out = np.zeros((n_el, 3))

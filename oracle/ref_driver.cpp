@@ -580,6 +580,13 @@ void ref_rad_trace_ray(void *h, long n, const double *o, const double *d, double
 		rgb[3 * k] = c.red; rgb[3 * k + 1] = c.green; rgb[3 * k + 2] = c.blue;
 	}
 }
+// Fills QuadTreeNode::nextAdj (the reference's own build of it is commented out, radiosity.cpp:167-199) with m records
+// "element ei[k] shares the point pts[3k..] with element ej[k]"; m = 0 clears every list.
+void ref_rad_set_adjacency(void *h, long m, const int *ei, const int *ej, const double *pts) {
+	RefScene *s = (RefScene *)h;
+	if (m == 0) for (QuadTreeNode *e : s->elems) e->nextAdj.clear();
+	for (long k = 0; k < m; ++k) s->elems[ei[k]]->nextAdj[s->elems[ej[k]]].insert(V(pts + 3 * k));
+}
 // returnQuadTreeColor (radiosity_helper.h:156-268) evaluated AT the three vertices of every element: there the
 // barycentric weights are exactly (1,0,0), (0,1,0), (0,0,1), so the result is the interpolated radiosity the reference
 // attaches to that vertex (shared-vertex averages over nextAdj) — out: n_elements × 3

@@ -934,8 +934,8 @@ void rto_tone_map(long n, const double *rgb, uint8_t *out) {
 /* ---- radiosity display path: Rasterizer::Radiosity_Raster (rasterizer.cpp:408-470) ------------------------- */
 /* calculatePseudoInverse (mat3x2.h:187-283) of the 3×2 matrix [v2−v1 | v3−v1] as returnUVofTriangle sets it up
  * (util.cpp:126-136): rows A, B with u = A·(p−v1), v = B·(p−v1).  Returns 0 when the reference reports "not invertible". */
-int rto_pinv(const double t[9], double A[3], double B[3]) {
-	const double m00 = t[3] - t[0], m01 = t[6] - t[0], m10 = t[4] - t[1], m11 = t[7] - t[1], m20 = t[5] - t[2], m21 = t[8] - t[2];
+static int rto_pinv_m(double m00, double m01, double m10, double m11, double m20, double m21, double A[3], double B[3]) {
+	A[0] = A[1] = A[2] = B[0] = B[1] = B[2] = 0.0;
 	const double x = m00 * m00 + m10 * m10 + m20 * m20;
 	const double z = m01 * m00 + m11 * m10 + m21 * m20;
 	const double y = m00 * m01 + m10 * m11 + m20 * m21;
@@ -974,6 +974,49 @@ int rto_pinv(const double t[9], double A[3], double B[3]) {
 	A[0] = i1x * U1.x + i1y * U2.x; A[1] = i1x * U1.y + i1y * U2.y; A[2] = i1x * U1.z + i1y * U2.z;
 	B[0] = i2x * U1.x + i2y * U2.x; B[1] = i2x * U1.y + i2y * U2.y; B[2] = i2x * U1.z + i2y * U2.z;
 	return 1;
+}
+int rto_pinv(const double t[9], double A[3], double B[3]) {
+	return rto_pinv_m(t[3] - t[0], t[6] - t[0], t[4] - t[1], t[7] - t[1], t[5] - t[2], t[8] - t[2], A, B);
+}
+
+/* centerOfTriangle (radiosity_helper.h:115-142) */
+static v3 rto_center(const double *t) {
+	v3 v1 = {t[0], t[1], t[2]}, v2 = {t[3], t[4], t[5]}, v3_ = {t[6], t[7], t[8]};
+	v3 l1 = sub(add(scl(0.5, sub(v3_, v2)), v2), v1);
+	v3 l2 = sub(add(scl(0.5, sub(v1, v3_)), v3_), v2);
+	double A[3], B[3];
+	rto_pinv_m(l1.x, -l2.x, l1.y, -l2.y, l1.z, -l2.z, A, B);
+	v3 d = sub(v2, v1);
+	const double tt = A[0] * d.x + A[1] * d.y + A[2] * d.z;
+	return add(scl(tt, l1), v1);
+}
+/* The vertex values of returnQuadTreeColor (radiosity_helper.h:172-213, :244-257) with nextAdj = "elements that have the same
+ * three doubles as a vertex" (the reference's own adjacency build is disabled, radiosity.cpp:167-199), adjacent elements
+ * taken in element order.  Plain O(n²) scan: the checker of rtmi_radiosity_vertex_values. */
+void rto_vertex_values(long n, const double *verts, const double *Bv, double *out) {
+	for (long e = 0; e < n; ++e) {
+		const v3 ce = rto_center(verts + 9 * e);
+		for (int k = 0; k < 3; ++k) {
+			const double *p = verts + 9 * e + 3 * k;
+			const v3 P = {p[0], p[1], p[2]};
+			double acc = 0.0;
+			long cnt = 0;
+			for (long a = 0; a < n; ++a) {
+				if (a == e) continue;
+				int shares = 0;
+				for (int q = 0; q < 3 && !shares; ++q) {
+					const double *w = verts + 9 * a + 3 * q;
+					shares = w[0] == p[0] && w[1] == p[1] && w[2] == p[2];
+				}
+				if (!shares) continue;
+				const v3 ca = rto_center(verts + 9 * a);
+				const double l1 = len(sub(ce, P)), l2 = len(sub(P, ca)), full = l1 + l2;
+				acc += ((1.0 - (l1 / full)) * Bv[e]) + ((1.0 - (l2 / full)) * Bv[a]);
+				++cnt;
+			}
+			out[3 * e + k] = cnt ? acc / cnt : Bv[e];
+		}
+	}
 }
 
 static double area3(v3 a, v3 b, v3 c) { return len(cross(sub(b, a), sub(c, a))) / 2.0; } /* vec3.h:116-118 */

@@ -87,7 +87,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_
 SYMBOLS = [
     "rtmi_last_error", "rtmi_device_count", "rtmi_triangle_intersection", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_get_info", "rtmi_scene_check",
     "rtmi_closest_hit", "rtmi_closest_hit_dev", "rtmi_camera_setup", "rtmi_primary_closest_hit_dev", "rtmi_primary_closest_hit_samples_dev",
-    "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev", "rtmi_shadow_occlusion_dev", "rtmi_debug_check_hierarchy", "rtmi_debug_form_factor_kernel", "rtmi_debug_form_factor_planes", "rtmi_debug_div3_dev",
+    "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev", "rtmi_shadow_occlusion_dev", "rtmi_debug_check_hierarchy", "rtmi_debug_form_factor_kernel", "rtmi_debug_form_factor_planes", "rtmi_debug_div3_dev", "rtmi_radiosity_vertex_values",
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev", "rtmi_radiosity_solve_noalloc_dev",
     "rtmi_comm_unique_id", "rtmi_comm_create", "rtmi_comm_destroy", "rtmi_radiosity_solve_sharded_dev",
@@ -134,6 +134,7 @@ def _load():
     L.rtmi_debug_check_hierarchy.argtypes = [vp, u64, vp]
     L.rtmi_debug_form_factor_kernel.argtypes = [vp]
     L.rtmi_debug_form_factor_planes.argtypes = [vp]
+    L.rtmi_radiosity_vertex_values.argtypes = [vp, u32, vp, vp]
     L.rtmi_debug_div3_dev.argtypes = [vp, vp, u64, vp, vp, vp]
     L.rtmi_occlusion_fraction_dev.argtypes = [vp, u64, u32, vp, vp]
     L.rtmi_soft_shadow_rays_dev.argtypes = [vp, vp, vp, vp, u64, vp, u32, vp, vp]
@@ -609,6 +610,8 @@ class Radiosity:
     # -- display path (Rasterizer::Radiosity_Raster, rasterizer.cpp:408-470)
     def _vertex_radiosity(self, vertex_radiosity):
         import torch
+        if isinstance(vertex_radiosity, str) and vertex_radiosity == "shared":   # returnQuadTreeColor's shared-vertex averages
+            vertex_radiosity = vertex_values(self.scene.tri_xyz, self.radiosityValue)
         if vertex_radiosity is None:      # flat: returnQuadTreeColor without shared-vertex averages = radiosityValue at every vertex
             vertex_radiosity = np.repeat(np.asarray(self.radiosityValue, np.float64)[:, None], 3, 1)
         vr = _np(vertex_radiosity, np.float64, (-1, 3))
@@ -640,6 +643,18 @@ class Radiosity:
                                              tile_stride, d_rgb.data_ptr(), d_pix.data_ptr(), torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         return (d_rgb.cpu().numpy().reshape(cam.y_res, cam.x_res, 3), d_pix.cpu().numpy().reshape(cam.y_res, cam.x_res, 3))
+
+
+def vertex_values(verts, B):
+    """returnQuadTreeColor's vertex values (radiosity_helper.h:156-213): n x 3, for elements verts [n][9] with radiosities B [n]
+    (host arrays; rtmi_radiosity_vertex_values)."""
+    verts = _np(verts, np.float64, (-1, 9))
+    B = _np(B, np.float64)
+    if len(B) != len(verts):
+        raise ValueError("one radiosity per element")
+    out = np.zeros((len(verts), 3))
+    _check(lib.rtmi_radiosity_vertex_values(_ptr(verts), len(verts), _ptr(B), _ptr(out)))
+    return out
 
 
 NOALLOC_MAX_N = 131072            # include/rtmi.h: RTMI_NOALLOC_MAX_N

@@ -5,6 +5,8 @@
 // once to fp32 for storage; the solve streams that fp32 matrix from HBM once per sweep.
 #include "rtmi_rad_device.hpp"
 
+#include <algorithm>
+
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -376,15 +378,10 @@ __global__ void k_tone_map_radiosity(const double *__restrict__ rgb, uint64_t n,
 	if (k < n) tone_radiosity(d3(rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]), pixels + 3 * k);
 }
 
-// calculatePseudoInverse (Render2/mat3x2.h:187-283) of [v2−v1 | v3−v1] (util.cpp:128-134), host side, same libm calls;
-// rec = the 16-double display record of one element
-static void display_record(const double *t, const double *nrm, double *rec) {
-	for (int a = 0; a < 3; ++a) { rec[a] = nrm[a]; rec[3 + a] = t[a]; }
-	double *A = rec + 6, *B = rec + 9;
-	for (int a = 0; a < 6; ++a) A[a] = 0.0;
-	rec[12] = ((-1.0 * nrm[0]) * t[0]) + ((-1.0 * nrm[1]) * t[1]) + ((-1.0 * nrm[2]) * t[2]); // (−1.0·n)·v1, radiosity_helper.cpp:332
-	rec[13] = 0.0; rec[14] = rec[15] = 0.0;
-	const double m00 = t[3] - t[0], m01 = t[6] - t[0], m10 = t[4] - t[1], m11 = t[7] - t[1], m20 = t[5] - t[2], m21 = t[8] - t[2];
+// calculatePseudoInverse (Render2/mat3x2.h:187-283) of the 3×2 matrix [m00 m01; m10 m11; m20 m21], host side, same libm
+// calls: rows A, B of the pseudo-inverse; false = "not an invertable matrix" (A, B left zero)
+static bool pinv3x2(double m00, double m01, double m10, double m11, double m20, double m21, double *A, double *B) {
+	for (int a = 0; a < 3; ++a) A[a] = B[a] = 0.0;
 	const double x = m00 * m00 + m10 * m10 + m20 * m20;
 	const double z = m01 * m00 + m11 * m10 + m21 * m20;
 	const double y = m00 * m01 + m10 * m11 + m20 * m21;
@@ -393,22 +390,21 @@ static void display_record(const double *t, const double *nrm, double *rec) {
 	e1 /= 2.0;
 	double e2 = (x + w) - std::sqrt(std::pow((x + w), 2) - (4.0 * ((x * w) - (y * z))));
 	e2 /= 2.0;
-	if (e1 == 0.0 || e2 == 0.0) return; // "not an invertable matrix": returnUVofTriangle then answers (0, 0)
-	rec[13] = 1.0;
+	if (e1 == 0.0 || e2 == 0.0) return false;
 	if (e1 == e2) {
 		A[0] = m00 / e1; A[1] = m10 / e1; A[2] = m20 / e1;
 		B[0] = m01 / e1; B[1] = m11 / e1; B[2] = m21 / e1;
-		return;
+		return true;
 	}
 	if (z == 0.0 && y == 0.0) {
 		A[0] = m00 / e1; A[1] = m10 / e1; A[2] = m20 / e1;
 		if (std::fabs((A[0] * m00 + A[1] * m10 + A[2] * m20) - 1.0) > kEpsilon) {
 			A[0] = m00 / e2; A[1] = m10 / e2; A[2] = m20 / e2;
 			B[0] = m01 / e1; B[1] = m11 / e1; B[2] = m21 / e1;
-			return;
+			return true;
 		}
 		B[0] = m01 / e2; B[1] = m11 / e2; B[2] = m21 / e2;
-		return;
+		return true;
 	}
 	const double l1x2 = std::fabs(x - e1), l1x1 = ((-1.0 * y) / (x - e1)) * l1x2;
 	const double l2x2 = std::fabs(x - e2), l2x1 = ((-1.0 * y) / (x - e2)) * l2x2;
@@ -427,6 +423,30 @@ static void display_record(const double *t, const double *nrm, double *rec) {
 	const double i1x = v1x * (1.0 / std::sqrt(e1)), i1y = v2x * (1.0 / std::sqrt(e2));
 	const double i2x = v1y * (1.0 / std::sqrt(e1)), i2y = v2y * (1.0 / std::sqrt(e2));
 	for (int a = 0; a < 3; ++a) { A[a] = i1x * U1[a] + i1y * U2[a]; B[a] = i2x * U1[a] + i2y * U2[a]; }
+	return true;
+}
+
+// [v2−v1 | v3−v1] as returnUVofTriangle sets it up (util.cpp:128-134); rec = the 16-double display record of one element
+static void display_record(const double *t, const double *nrm, double *rec) {
+	for (int a = 0; a < 3; ++a) { rec[a] = nrm[a]; rec[3 + a] = t[a]; }
+	rec[12] = ((-1.0 * nrm[0]) * t[0]) + ((-1.0 * nrm[1]) * t[1]) + ((-1.0 * nrm[2]) * t[2]); // (−1.0·n)·v1, radiosity_helper.cpp:332
+	rec[14] = rec[15] = 0.0;
+	// "not an invertable matrix": returnUVofTriangle then answers (0, 0)
+	rec[13] = pinv3x2(t[3] - t[0], t[6] - t[0], t[4] - t[1], t[7] - t[1], t[5] - t[2], t[8] - t[2], rec + 6, rec + 9) ? 1.0 : 0.0;
+}
+
+// centerOfTriangle (Render2/radiosity_helper.h:115-142): where the medians from triVert1 and triVert2 cross, through the
+// pseudo-inverse of [VLine1 | −VLine2]
+static void center_of_triangle(const double *t, double *c) {
+	double l1[3], l2[3];
+	for (int a = 0; a < 3; ++a) {
+		l1[a] = ((0.5 * (t[6 + a] - t[3 + a])) + t[3 + a]) - t[a];
+		l2[a] = ((0.5 * (t[a] - t[6 + a])) + t[6 + a]) - t[3 + a];
+	}
+	double A[3], B[3];
+	pinv3x2(l1[0], -l2[0], l1[1], -l2[1], l1[2], -l2[2], A, B);
+	const double tt = A[0] * (t[3] - t[0]) + A[1] * (t[4] - t[1]) + A[2] * (t[5] - t[2]);
+	for (int a = 0; a < 3; ++a) c[a] = (tt * l1[a]) + t[a];
 }
 
 // the BVH pays from a few hundred elements on; RTMI_DISPLAY_QUERY=1 forces the loop over all elements, =2 the BVH
@@ -854,6 +874,64 @@ int rtmi_radiosity_trace_dev(rtmi_patches *P, const double *d_vertex_radiosity, 
 		hipLaunchKernelGGL(k_display_rays<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P->scene->dev, V, d_vertex_radiosity,
 		                   d_rays, n, d_rgb);
 	return launch_check(who);
+}
+
+// returnQuadTreeColor's vertex values (Render2/radiosity_helper.h:156-213), see include/rtmi.h.  Host only.
+int rtmi_radiosity_vertex_values(const double *verts, uint32_t n, const double *B, double *out) {
+	const char *who = "rtmi_radiosity_vertex_values";
+	if (n == 0) return 0;
+	if (!verts || !B || !out) return fail(std::string(who) + ": NULL argument");
+	try {
+		std::vector<double> centre(3 * (size_t)n);
+		for (uint32_t e = 0; e < n; ++e) center_of_triangle(verts + 9 * (size_t)e, centre.data() + 3 * (size_t)e);
+		// who has this vertex: corners sorted by their three doubles (−0 = +0), then by element — the order they are summed in
+		struct Corner { double p[3]; uint32_t e; };
+		std::vector<Corner> corners(3 * (size_t)n);
+		for (uint32_t e = 0; e < n; ++e)
+			for (int k = 0; k < 3; ++k) {
+				Corner &c = corners[3 * (size_t)e + k];
+				for (int a = 0; a < 3; ++a) c.p[a] = verts[9 * (size_t)e + 3 * k + a] + 0.0;
+				c.e = e;
+			}
+		auto less = [](const Corner &x, const Corner &y) {
+			for (int a = 0; a < 3; ++a) if (x.p[a] != y.p[a]) return x.p[a] < y.p[a];
+			return x.e < y.e;
+		};
+		std::sort(corners.begin(), corners.end(), less);
+		auto same = [](const Corner &x, const Corner &y) { return x.p[0] == y.p[0] && x.p[1] == y.p[1] && x.p[2] == y.p[2]; };
+		auto length = [](const double *a, const double *b) { // Length(a − b), vec3.h:14
+			const double x = a[0] - b[0], y = a[1] - b[1], z = a[2] - b[2];
+			return std::sqrt(x * x + y * y + z * z);
+		};
+		for (size_t lo = 0; lo < corners.size();) {
+			size_t hi = lo + 1;
+			while (hi < corners.size() && same(corners[lo], corners[hi])) ++hi;
+			for (size_t q = lo; q < hi; ++q) {
+				const uint32_t e = corners[q].e;
+				if (q > lo && corners[q - 1].e == e) continue; // a degenerate element with the point twice: handled with its first corner
+				const double *p = corners[q].p, *ce = centre.data() + 3 * (size_t)e;
+				double acc = 0.0;
+				uint32_t cnt = 0;
+				for (size_t r = lo; r < hi; ++r) {
+					const uint32_t a = corners[r].e;
+					if (a == e || (r > lo && corners[r - 1].e == a)) continue;
+					const double *ca = centre.data() + 3 * (size_t)a;
+					const double l1 = length(ce, p), l2 = length(p, ca), full = l1 + l2;              // :200
+					acc += ((1.0 - (l1 / full)) * B[e]) + ((1.0 - (l2 / full)) * B[a]);               // :202-203
+					++cnt;                                                                             // :205
+				}
+				const double value = cnt ? acc / cnt : B[e];                                          // :212, :255-257
+				for (int k = 0; k < 3; ++k) {
+					const double *v = verts + 9 * (size_t)e + 3 * k;
+					if (v[0] + 0.0 == p[0] && v[1] + 0.0 == p[1] && v[2] + 0.0 == p[2]) out[3 * (size_t)e + k] = value;
+				}
+			}
+			lo = hi;
+		}
+		return 0;
+	} catch (const std::exception &ex) {
+		return fail(std::string(who) + ": " + ex.what());
+	}
 }
 
 int rtmi_radiosity_raster_dev(rtmi_patches *P, const double *d_vertex_radiosity, const rtmi_camera *cam, double sx, double sy,

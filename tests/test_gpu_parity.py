@@ -856,6 +856,11 @@ def test_radiosity_display_path(rt, oracle, stem):
     assert np.array_equal(np.where(a != 0, a, b), rgb)
     flat, _ = rad.Radiosity_Raster(cam)
     assert np.array_equal(flat.reshape(-1, 3), oracle.radiosity_trace(G("verts"), G("normals"), np.repeat(G("B")[:, None], 3, 1), o, d))
+    # smooth shading without the reference host: the library's own shared-vertex averages (rtmi_radiosity_vertex_values,
+    # pinned by g10 to the reference's returnQuadTreeColor) through the same display kernels
+    smooth, _ = rad.Radiosity_Raster(cam, "shared")
+    assert np.array_equal(smooth.reshape(-1, 3), oracle.radiosity_trace(G("verts"), G("normals"), oracle.vertex_values(G("verts"), G("B")), o, d))
+    assert (smooth != flat).any()
 
 
 def test_radiosity_display_bvh_equals_the_full_loop(rt, oracle, monkeypatch):

@@ -319,6 +319,22 @@ def test_g8_radiosity_display_path(oracle, stem):
     assert green.any() and (~green & (rgb[:, 0] > 0)).sum() > 1000
 
 
+@pytest.mark.parametrize("stem", ["radiosity_test", "practice_room_enclosed", "sheet"])
+def test_g10_vertex_values_of_returnQuadTreeColor(oracle, stem):
+    """The radiosity returnQuadTreeColor (radiosity_helper.h:156-268) attaches to an element's vertices, as the compiled
+    reference's own function gave it with QuadTreeNode::nextAdj = "the elements that share this vertex"
+    (oracle/gen_golden_vertex.py fills it; the reference's own build of it is commented out, radiosity.cpp:167-199).
+    Tolerance 1e-15 relative: the reference multiplies the vertex's value by its area weight Area(v2, v1, v3) / Area(v1, v2, v3)
+    (:235-238), which is 1 up to one rounding at the second and third vertex."""
+    g = load_golden("g10_vertex_values.npz")
+    G = lambda k: g[stem + "/" + k]
+    mine = oracle.vertex_values(G("verts"), G("B"))
+    ref = G("vertex_values")
+    assert np.allclose(mine, ref, rtol=1e-15, atol=0)
+    flat = np.repeat(G("B")[:, None], 3, 1)
+    assert (np.abs(ref - flat) > 1e-6).sum() > 0.9 * ref.size and int(G("n_adjacency")) > 50   # the averages are not the flat values
+
+
 def test_g9_radiosity_branch_of_shade_bit_exact(oracle):
     """Shader::Shade with scene.radiosity != NULL (shader.cpp:431-478) as the compiled reference ran it
     (oracle/gen_golden_radshade.py): the restatement's colours equal the reference's bit for bit — on the studio scene (all six
