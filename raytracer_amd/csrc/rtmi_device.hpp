@@ -246,6 +246,35 @@ __device__ __forceinline__ int sbyte(uint32_t w, int k) { return (int)(w << (24 
 // (farthest first), or pop.  Returns the lane's next reference (inner node, raw leaf reference, or kSentinel).
 // A hit child is carried as ONE sortable word: the bits of its entry distance (>= 0, so they order like the float) with
 // the child's number in the two lowest bits; 0xffffffff = not hit.  Five min/max pairs sort the four words.
+#ifndef RTMI_PAIR_FETCH
+#define RTMI_PAIR_FETCH 0
+#endif
+// RTMI_PAIR_FETCH=1 (experiment, profiles/ab_r03.md): neighbouring lanes 2k, 2k+1 fetch their two nodes together.  Every lane
+// loads piece a of its own node; then the pair loads pieces b and c of the even lane's node with ONE instruction (the two
+// addresses are neighbours in one cache line seven times in eight) and b and c of the odd lane's node with another; a
+// quad_perm swap hands each lane the piece its neighbour fetched for it.  Four cache-line look-ups per pair and visit
+// instead of six, for about twenty more vector instructions.  Must be called by every lane of the wave.
+__device__ __forceinline__ int dpp_swap_neighbour(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); } // quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ uint4 dpp_swap_neighbour(uint4 v) {
+	return make_uint4((uint32_t)dpp_swap_neighbour((int)v.x), (uint32_t)dpp_swap_neighbour((int)v.y), (uint32_t)dpp_swap_neighbour((int)v.z),
+	                  (uint32_t)dpp_swap_neighbour((int)v.w));
+}
+__device__ __forceinline__ void pair_fetch(const SceneDev &S, int cur, uint32_t lane, uint4 &a, uint4 &b, uint4 &c) {
+	const bool odd = (lane & 1u) != 0u;
+	const int pcur = dpp_swap_neighbour(cur);
+	const int n0 = odd ? pcur : cur, n1 = odd ? cur : pcur; // the even lane's node, the odd lane's node
+	const uint4 *base = reinterpret_cast<const uint4 *>(S.wnodes);
+	uint4 r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1;
+	if (cur >= 0) r1 = base[3 * (size_t)(uint32_t)cur];                       // a of my own node
+	if (n0 >= 0) r2 = base[3 * (size_t)(uint32_t)n0 + (odd ? 2u : 1u)];      // even: b(n0), odd: c(n0)
+	if (n1 >= 0) r3 = base[3 * (size_t)(uint32_t)n1 + (odd ? 2u : 1u)];      // even: b(n1), odd: c(n1)
+	const uint4 x = dpp_swap_neighbour(r2), y = dpp_swap_neighbour(r3);
+	a = r1;
+	b = odd ? y : r2;  // odd: the b(n1) its neighbour fetched
+	c = odd ? r3 : x;  // even: the c(n0) its neighbour fetched
+}
+
+__device__ __forceinline__ int node_step_abc(const SceneDev &S, const RayW &r, float tbest, uint4 a, uint4 b, uint4 c, int &sp, int *stack);
 __device__ __forceinline__ int node_step(const SceneDev &S, const RayW &r, float tbest, int cur, int &sp, int *stack, const WNode *top = nullptr,
                                          uint32_t n_top = 0) {
 #ifdef RTMI_NODE_STRIDE // experiment: nodes at a stride of 64 B (none straddles a cache line), 48 B of each used
@@ -259,6 +288,9 @@ __device__ __forceinline__ int node_step(const SceneDev &S, const RayW &r, float
 	else
 #endif
 	{ a = np->a; b = np->b; c = np->c; }
+	return node_step_abc(S, r, tbest, a, b, c, sp, stack);
+}
+__device__ __forceinline__ int node_step_abc(const SceneDev &S, const RayW &r, float tbest, uint4 a, uint4 b, uint4 c, int &sp, int *stack) {
 	const float ax = ldexpf(r.ix, sbyte(a.w, 0)), ay = ldexpf(r.iy, sbyte(a.w, 1)), az = ldexpf(r.iz, sbyte(a.w, 2));
 	const float px = __uint_as_float(a.x), py = __uint_as_float(a.y), pz = __uint_as_float(a.z);
 	const float bnx = fmaf(px, r.ix, r.cnx), bny = fmaf(py, r.iy, r.cny), bnz = fmaf(pz, r.iz, r.cnz);
@@ -448,6 +480,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 #else
 	const WNode *top = nullptr;
 	const uint32_t n_top = 0;
+	(void)top; (void)n_top;
 #endif
 	__shared__ unsigned long long pool_word;
 	__shared__ uint32_t pool_seen_word;
@@ -794,10 +827,20 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 					if (cur < 0 && cur != kSentinel) ++w->wait_leaf;     // holds a leaf, waits for a triangle round
 					else if (cur == kSentinel) ++w->wait_idle;            // finished or without a ray, waits for the refill
 				}
+#if RTMI_PAIR_FETCH
+				if (__ballot(cur >= 0) == 0ull) break; // nobody has a node left this round (wave-uniform)
+				uint4 na, nb, nc;
+				pair_fetch(S, cur, lane, na, nb, nc);
+				if (cur >= 0) {
+					if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
+					cur = node_step_abc(S, r, tbest, na, nb, nc, sp, stack);
+				}
+#else
 				if (cur >= 0) {
 					if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
 					cur = node_step(S, r, tbest, cur, sp, stack, top, n_top);
 				}
+#endif
 			}
 		} else {
 			if (cur == kLeaf) {
