@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 namespace rtmi {
@@ -248,6 +249,9 @@ RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx
 #ifndef RTMI_FF_SKIP_MT
 #define RTMI_FF_SKIP_MT 1
 #endif
+#ifndef RTMI_FF_SAME_PLANE
+#define RTMI_FF_SAME_PLANE 1
+#endif
 // Workgroup = ONE group of 64 patches j (blockIdx.x); its four waves take four consecutive bands of rows i, so the group's
 // per-lane tables are fetched once per workgroup and shared through the L1.  Columns j < n_patches only; the light's row
 // (i == n_patches) is zero (:391-393), the diagonal too (:382).
@@ -256,7 +260,7 @@ RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx
 // them, and fetches everything that depends on i alone with scalar loads.)
 RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const double *__restrict__ p_verts, const double *__restrict__ p_normals,
                                                            const double *__restrict__ p_area, uint32_t p_n, const ChainEntry *__restrict__ t_chain,
-                                                           const PatchMeta *__restrict__ t_meta, const uint32_t *__restrict__ t_dfs, const float2 *__restrict__ t_gconst,
+                                                           const PatchMeta *__restrict__ t_meta, const uint32_t *__restrict__ t_dfs, const uint4 *__restrict__ t_gconst,
                                                            uint32_t samples, uint64_t seed, uint32_t row0, uint32_t n_rows, uint32_t band_rows,
                                                            float margin, double graze_cos_i, double graze_cos_j, uint32_t planes_on, uint32_t pend_cap, uint32_t n_groups, float *__restrict__ F, uint64_t ld) {
 	struct { const double *verts, *normals, *area; uint32_t n; } P = {p_verts, p_normals, p_area, p_n};
@@ -297,12 +301,20 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 	const uint32_t behind_j = mj.behind & bits_below(dj);
 	const uint32_t cand_shared = wave_or_u32(~mj.behind & low), behind_shared = wave_or_u32(mj.behind & low);
 	// the group's two constants of the "certain hit" test below (host: build_ff_tables), wave-uniform
-	const float2 gconst = t_gconst[g];
-	const double sure_margin = (double)gconst.x, sure_cos = (double)gconst.y;
+	const uint4 gconst = t_gconst[g];
+	const double sure_margin = (double)__uint_as_float(gconst.x), sure_cos = (double)__uint_as_float(gconst.y);
+	// Same-plane rows (host: build_ff_tables): gkey != 0 = every patch of this group lies in ONE axis-parallel plane whose
+	// coordinate is exact in every sample point (<= 20 significant bits: w·z + u·z + v·z = z with no rounding, w, u, v being
+	// multiples of 2^-32 that sum to 1) and has an axis normal; a row i with the same key then has xj − xi exactly 0 along that
+	// axis for every sample, hence cos_i = ±0, no sample counts (:320-324) and F(i, j) = 0 for the whole group — a sixth of a
+	// box's matrix, ten samples each, without evaluating one of them.  (The root-traversal kernel and the oracle compute those
+	// zeros; tests compare.)
+	const uint32_t gkey = RTMI_FF_SAME_PLANE ? gconst.z : 0u;
+	const uint32_t *t_pkey = reinterpret_cast<const uint32_t *>(t_gconst + n_groups);
 	for (uint32_t r = r_begin; r < r_end; ++r) {
 		const uint32_t i = row0 + r; // wave-uniform
 		double out = 0.0;
-		if (i < P.n) {
+		if (i < P.n && !(gkey != 0u && t_pkey[i] == gkey)) {
 			const PatchMeta mi = T.meta[i];
 			const uint32_t di = meta_depth(mi), leaf_i = meta_leafpos(mi);
 			const double *ei = P.verts + 9 * (size_t)i;
@@ -763,7 +775,33 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	// smallest altitude and edge the longest edge of a patch,
 	//   sure_margin = 1e-12·(1 + |coord|max)·max (1 + edge)/a     sure_cos = max(graze_cos, max 1.01e-8/(2A))
 	// rounded up to float; a patch without area makes both infinite (its group then always runs the exact test).
-	std::vector<float> gconst(2 * (size_t)n_groups);
+	// Same-plane keys (k_form_factors): patch id gets key k >= 1 iff its caller normal is exactly ± a coordinate axis, its three
+	// vertices have the very same coordinate z along that axis, and z has at most 20 significant bits (every sample point of the
+	// patch then has exactly z there); the key numbers the (axis, z) pairs.  A group's key is its patches' common key, else 0.
+	std::vector<uint32_t> pkey(n, 0u);
+	{
+		std::unordered_map<uint64_t, uint32_t> ids[3];
+		for (uint32_t id = 0; id < n; ++id) {
+			const double *v = h_verts.data() + 9 * (size_t)id, *nr = h_normals.data() + 3 * (size_t)id;
+			for (int a = 0; a < 3; ++a) {
+				const int b = (a + 1) % 3, c = (a + 2) % 3;
+				if (!(std::fabs(nr[a]) == 1.0 && nr[b] == 0.0 && nr[c] == 0.0)) continue;
+				const double z = v[a] + 0.0;
+				if (!(v[3 + a] == z && v[6 + a] == z) || !std::isfinite(z)) continue;
+				int e = 0;
+				const double m = std::frexp(z, &e) * 1048576.0; // 2^20
+				if (m != std::floor(m)) continue;
+				uint64_t bits;
+				std::memcpy(&bits, &z, sizeof bits);
+				auto it = ids[a].find(bits);
+				if (it == ids[a].end()) it = ids[a].emplace(bits, (uint32_t)(ids[0].size() + ids[1].size() + ids[2].size() + 1)).first;
+				pkey[id] = it->second;
+			}
+		}
+	}
+	std::vector<uint32_t> gconst(4 * (size_t)n_groups + n, 0u);
+	auto f32_bits = [](float f) { uint32_t u; std::memcpy(&u, &f, sizeof u); return u; };
+	for (uint32_t id = 0; id < n; ++id) gconst[4 * (size_t)n_groups + id] = pkey[id];
 	for (uint32_t g = 0; g < n_groups; ++g) {
 		double margin = 0.0, cosmin = graze_cos;
 		for (uint32_t k = 0; k < 64u; ++k) {
@@ -778,17 +816,26 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 			margin = std::max(margin, 1e-12 * (1.0 + (double)s->dev.absmax) * (1.0 + edge) * edge / twoA);
 			cosmin = std::max(cosmin, 1.01e-8 / twoA);
 		}
-		gconst[2 * (size_t)g] = f32_above_h(margin);
-		gconst[2 * (size_t)g + 1] = f32_above_h(cosmin);
+		gconst[4 * (size_t)g] = f32_bits(f32_above_h(margin));
+		gconst[4 * (size_t)g + 1] = f32_bits(f32_above_h(cosmin));
+		uint32_t key = 0u;
+		bool first = true;
+		for (uint32_t k = 0; k < 64u; ++k) {
+			const uint32_t id = W.dfs[(size_t)g * 64u + k];
+			if (id == RTMI_MISS) continue;
+			if (first) { key = pkey[id]; first = false; }
+			else if (pkey[id] != key) key = 0u;
+		}
+		gconst[4 * (size_t)g + 2] = key;
 	}
 	void *d_chain = nullptr, *d_meta = nullptr, *d_gconst = nullptr;
 	uint32_t *d_dfs = nullptr;
 	bool ok = hipMalloc(&d_chain, W.chain.size() * sizeof(ChainEntry)) == hipSuccess && hipMalloc(&d_meta, (size_t)n * sizeof(PatchMeta)) == hipSuccess &&
-	          hipMalloc(&d_dfs, W.dfs.size() * sizeof(uint32_t)) == hipSuccess && hipMalloc(&d_gconst, gconst.size() * sizeof(float)) == hipSuccess;
+	          hipMalloc(&d_dfs, W.dfs.size() * sizeof(uint32_t)) == hipSuccess && hipMalloc(&d_gconst, gconst.size() * sizeof(uint32_t)) == hipSuccess;
 	ok = ok && hipMemcpy(d_chain, W.chain.data(), W.chain.size() * sizeof(ChainEntry), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(d_meta, W.meta.data(), (size_t)n * sizeof(PatchMeta), hipMemcpyHostToDevice) == hipSuccess &&
 	     hipMemcpy(d_dfs, W.dfs.data(), W.dfs.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess &&
-	     hipMemcpy(d_gconst, gconst.data(), gconst.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+	     hipMemcpy(d_gconst, gconst.data(), gconst.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
 	if (!ok) {
 		if (d_chain) (void)hipFree(d_chain);
 		if (d_meta) (void)hipFree(d_meta);
@@ -857,7 +904,7 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		const uint32_t lds = (s->info.max_depth + 1u + pend_cap) * kBlock * (uint32_t)sizeof(int);
 		hipLaunchKernelGGL(k_form_factors, grid, dim3(kBlock), lds, st, s->dev, (const double *)P->d_verts, (const double *)P->d_normals,
 		                   (const double *)P->d_area, P->n, static_cast<const ChainEntry *>(P->d_chain), static_cast<const PatchMeta *>(P->d_meta),
-		                   P->d_dfs, static_cast<const float2 *>(P->d_gconst), samples, seed, first, count, band, margin, P->graze_cos_i, P->graze_cos_j, P->plane_delta >= 0.0 ? 1u : 0u, pend_cap, P->n_groups, out, ld);
+		                   P->d_dfs, static_cast<const uint4 *>(P->d_gconst), samples, seed, first, count, band, margin, P->graze_cos_i, P->graze_cos_j, P->plane_delta >= 0.0 ? 1u : 0u, pend_cap, P->n_groups, out, ld);
 		return launch_check(who);
 	};
 	int kernel = 0;

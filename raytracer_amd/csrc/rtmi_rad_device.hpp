@@ -22,7 +22,7 @@ struct rtmi_patches {
 	void *d_chain = nullptr;   // ChainEntry[]: per patch, the siblings along its root-to-leaf path
 	void *d_meta = nullptr;    // PatchMeta[n]
 	uint32_t *d_dfs = nullptr; // patch ids in depth-first leaf order, padded with RTMI_MISS to a multiple of 64
-	void *d_gconst = nullptr;  // float2[n_groups]: the "certain hit" constants of each group (rtmi_formfactor.hip: sure_margin, sure_cos)
+	void *d_gconst = nullptr;  // uint4[n_groups] {sure_margin, sure_cos (float bits), same-plane key, 0} + uint32[n] per-patch same-plane keys (rtmi_formfactor.hip)
 	uint32_t n_groups = 0;     // 64-patch groups of d_dfs
 	uint64_t chain_entries = 0;
 	double plane_delta = -1.0; // tolerance of the "behind the patch's plane" tests, < 0: the tests are off
