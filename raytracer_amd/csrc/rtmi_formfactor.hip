@@ -103,7 +103,7 @@ __device__ unsigned long long g_ff_counts[96];
 // there, and the sibling is dropped for all samples of the pair.  This is what disposes of the big boxes at the top of a
 // room's hierarchy (pieces of several flat walls in one box = a hollow volume the rays cross).
 #ifndef RTMI_FF_BEAM_BUDGET
-#define RTMI_FF_BEAM_BUDGET 12
+#define RTMI_FF_BEAM_BUDGET 3
 #endif
 constexpr int kBeamBudget = RTMI_FF_BEAM_BUDGET;
 __device__ __forceinline__ bool beam_meets_leaf(const SceneDev &S, int ref, const RayS &beam, int *stack) {
