@@ -526,6 +526,39 @@ def test_soup_closest_and_any_hit_vs_brute_force(rt, oracle, n_tris, n_rays):
         assert (tri >= 0).sum() > 1000
 
 
+def test_ragged_launch_sizes_through_the_shared_queue(rt, oracle):
+    """The traversal queue hands out items in claims that the waves of a workgroup share, 64 at a time, with sizes that follow
+    the measured rate (rtmi_device.hpp: trace_queue): every ray of launches of 1 ... 70 001 rays — counts around the multiples of
+    64, 256 and the claim sizes — gets exactly its own record (closest and any hit against the oracle's scan), and frames of odd sizes
+    dealt over three ranks are written exactly once.  (Claim sizes pinned to 64 ... 2048 with RTMI_CHUNK gave the same frame
+    digest in the sweeps of profiles/ab_r03.md; the variable is read once per process, so it is not varied here.)"""
+    from raytracer_amd import workloads
+    tris = workloads.soup(2000, seed=9, edge=0.15)
+    rng = np.random.default_rng(17)
+    n_max = 70001
+    o = rng.uniform(-1.5, 1.5, (n_max, 3))
+    d = rng.normal(size=(n_max, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    tmax = np.where(rng.random(n_max) < 0.5, 1e20, rng.uniform(0.1, 3.0, n_max))
+    tri, t, u, v = oracle.closest_hit(tris, o, d, tmax)
+    occ = oracle.any_hit(tris, o, d, tmax)
+    scene = rt.Scene(tris)
+    for n in (1, 2, 63, 64, 65, 127, 129, 255, 256, 257, 511, 1023, 1025, 4097, 16385, 65537, n_max):
+        got = scene.Cast(rt.make_rays(o[:n], d[:n], tmax[:n]))
+        assert np.array_equal(got["tri"], ids(tri[:n])) and np.array_equal(got["t"], t[:n]), n
+        assert np.array_equal(scene.Occluded(rt.make_rays(o[:n], d[:n], tmax[:n])), occ[:n]), n
+    cam14 = np.array([0, 0, -3, 0, 0, 0, 0, 1, 0, 2.75, -1.6, 1.6, -0.9, 0.9], np.float64)
+    for res in ((61, 37), (130, 67), (257, 129)):
+        cam = rt.Camera.from_cam14(cam14, res)
+        full = primary_frame(rt, scene, cam, tile=(0, 0))
+        parts = [primary_frame(rt, scene, cam, tile=(16, 16), tile_first=r, tile_stride=3, fill=0xAB) for r in range(3)]
+        raw = [p.view(np.uint8).reshape(-1, 24) for p in parts]
+        written = np.stack([(r != 0xAB).any(axis=1) for r in raw])
+        assert np.array_equal(written.sum(0), np.ones(len(full), np.int64)), res
+        union = np.where(written[0][:, None], raw[0], np.where(written[1][:, None], raw[1], raw[2]))
+        assert union.tobytes() == full.tobytes(), res
+
+
 @pytest.mark.parametrize("case", ["n2", "n3", "n4", "n6", "n7", "n9", "n17", "offset", "flat", "mixed_scales", "axis_rays"])
 def test_wide_node_layouts_vs_brute_force(rt, oracle, case):
     """The 4-wide hierarchy's corner cases (rtmi_device.hpp WNode): nodes with 2 or 3 children, leaves beside inner
