@@ -40,7 +40,10 @@ struct Box {
 	}
 };
 
-constexpr int NBINS = 16;
+#ifndef RTMI_NBINS
+#define RTMI_NBINS 16
+#endif
+constexpr int NBINS = RTMI_NBINS;
 
 struct Builder {
 	const std::vector<TriBox> &tb;
