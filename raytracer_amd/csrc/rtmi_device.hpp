@@ -816,7 +816,13 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 		// no lane ever runs ahead speculatively and the visited set is exactly the sequential one.
 		const int n_node = __popcll(__ballot(cur >= 0)), n_leaf = __popcll(__ballot(cur == kLeaf));
 		if (n_node + n_leaf == 0) { // nobody can step: finished lanes retire at the top of the next round
-			if (!more && __ballot(have) == 0ull) break;
+			if (!more && __ballot(have) == 0ull) {
+				if (kPool) { // a wave of this workgroup may have shared the rest of an earlier claim since this one last looked
+					const unsigned long long v = __hip_atomic_load(pool, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if ((uint32_t)v < (uint32_t)(v >> 32)) { more = true; continue; }
+				}
+				break;
+			}
 			continue;
 		}
 		if (n_node * vote_node >= n_leaf * vote_leaf) {
