@@ -66,7 +66,10 @@ constexpr int kLeaf = INT32_MIN + 1;      // lane state: working through the tri
 #ifndef RTMI_POOL
 #define RTMI_POOL 1
 #endif
-constexpr uint32_t kPoolTake = 64;        // items a wave moves from the shared range into its own at a time
+#ifndef RTMI_POOL_TAKE
+#define RTMI_POOL_TAKE 64
+#endif
+constexpr uint32_t kPoolTake = RTMI_POOL_TAKE;        // items a wave moves from the shared range into its own at a time
 constexpr bool kPool = RTMI_POOL != 0;    // the waves of a workgroup share what they claim from the launch's queue (trace_queue)
 constexpr bool kSplit = RTMI_SPLIT != 0;  // closest-hit queues: once a wave has no items left, its idle lanes take subtrees off the busy lanes' stacks (trace_queue)
 #ifndef RTMI_SPLIT_PAIRS

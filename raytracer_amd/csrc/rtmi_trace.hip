@@ -178,22 +178,38 @@ __device__ __forceinline__ D3 primary_dir(const rtmi_camera &c, uint32_t i, uint
 	return unit((O + (j + sx) * dR) - (i + sy) * dU);
 }
 
+// Division of a work-item index (< 2^31) by a launch constant: q = mulhi(n, m) >> k with m = ceil(2^(32+k) / d), k = floor(log2 d)
+// (exact for n < 2^31: m·d = 2^(32+k) + e with e < d <= 2^(k+1), so the error n·e / (d·2^(32+k)) stays below 1/d); powers of two
+// (m = 0) shift.  The compiler's division by a run-time value is ≈ 28 instructions; an item -> pixel mapping has five of them, and
+// it runs when a ray is fetched and again when its record is written — at the lane occupancy of a refill.
+struct FastDiv { uint32_t d, m, k; };
+static FastDiv make_fastdiv(uint32_t d) {
+	FastDiv f = {d ? d : 1u, 0u, 0u};
+	while ((2u << f.k) <= f.d && f.k < 31u) ++f.k; // k = floor(log2 d)
+	if ((f.d & (f.d - 1u)) != 0u) f.m = (uint32_t)((((unsigned long long)1 << (32 + f.k)) + f.d - 1u) / f.d);
+	return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) { return f.m ? (__umulhi(n, f.m) >> f.k) : (n >> f.k); }
+
 struct PrimaryGrid {
 	uint32_t tile_w, tile_h, tiles_x, tile_first, tile_stride, n_tiles;
 	uint32_t blk_w, blk_h;            // pixels one workgroup owns (multiples of 8)
 	uint32_t blocks_x, blocks_per_tile;
+	FastDiv d_per_block, d_blocks_per_tile, d_tiles_x, d_blocks_x, d_sq_x; // blk_w·blk_h, blocks_per_tile, tiles_x, blocks_x, blk_w / 8
 };
 
 // item k of a workgroup's blk_w × blk_h pixel block: consecutive runs of 64 items are 8×8 pixel squares, so
 // the rays a wave claims together are neighbours and walk the same nodes.
-__device__ __forceinline__ bool primary_pixel(const PrimaryGrid &g, const rtmi_camera &cam, uint32_t block, uint32_t k,
-                                              uint32_t &i, uint32_t &j) {
-	const uint32_t local_tile = block / g.blocks_per_tile, b = block % g.blocks_per_tile;
+__device__ __forceinline__ bool primary_pixel(const PrimaryGrid &g, const rtmi_camera &cam, uint32_t item, uint32_t &i, uint32_t &j) {
+	const uint32_t block = fdiv(item, g.d_per_block), k = item - block * g.d_per_block.d;
+	const uint32_t local_tile = fdiv(block, g.d_blocks_per_tile), b = block - local_tile * g.blocks_per_tile;
 	const uint32_t tile = g.tile_first + local_tile * g.tile_stride;
-	const uint32_t tx = tile % g.tiles_x, ty = tile / g.tiles_x;
-	const uint32_t sq = k >> 6, in = k & 63u, sq_x = g.blk_w >> 3;
-	const uint32_t lx = (b % g.blocks_x) * g.blk_w + (sq % sq_x) * 8 + (in & 7u);
-	const uint32_t ly = (b / g.blocks_x) * g.blk_h + (sq / sq_x) * 8 + (in >> 3);
+	const uint32_t ty = fdiv(tile, g.d_tiles_x), tx = tile - ty * g.tiles_x;
+	const uint32_t sq = k >> 6, in = k & 63u;
+	const uint32_t by = fdiv(b, g.d_blocks_x), bx = b - by * g.blocks_x;
+	const uint32_t sy = fdiv(sq, g.d_sq_x), sx = sq - sy * g.d_sq_x.d;
+	const uint32_t lx = bx * g.blk_w + sx * 8 + (in & 7u);
+	const uint32_t ly = by * g.blk_h + sy * 8 + (in >> 3);
 	j = tx * g.tile_w + lx;
 	i = ty * g.tile_h + ly;
 	return tile < g.n_tiles && lx < g.tile_w && ly < g.tile_h && j < cam.x_res && i < cam.y_res;
@@ -204,10 +220,9 @@ RTMI_TRAVERSAL_KERNEL void k_primary_closest(SceneDev S, int *__restrict__ count
                                                             double sx, double sy, PrimaryGrid g, Tune tune,
                                                             rtmi_hit *__restrict__ out) {
 	extern __shared__ int stack[];
-	const uint32_t per_block = g.blk_w * g.blk_h; // item -> (pixel block, pixel within the block)
 	auto fetch = [&](uint32_t idx, RayD &R) {
 		uint32_t i, j;
-		if (!primary_pixel(g, cam, idx / per_block, idx % per_block, i, j)) return false;
+		if (!primary_pixel(g, cam, idx, i, j)) return false;
 		const D3 d = primary_dir(cam, i, j, sx, sy);
 		R.dx = d.x; R.dy = d.y; R.dz = d.z;
 		R.tmax = RTMI_INFINITY;
@@ -215,7 +230,7 @@ RTMI_TRAVERSAL_KERNEL void k_primary_closest(SceneDev S, int *__restrict__ count
 	};
 	auto emit = [&](uint32_t idx, const HitQ &h, RayD &) {
 		uint32_t i, j;
-		primary_pixel(g, cam, idx / per_block, idx % per_block, i, j);
+		primary_pixel(g, cam, idx, i, j);
 		out[(uint64_t)i * cam.x_res + j] = hit_record(S, h);
 		return false;
 	};
@@ -228,6 +243,7 @@ RTMI_TRAVERSAL_KERNEL void k_primary_closest(SceneDev S, int *__restrict__ count
 struct SampleSet {
 	rtmi_primary_sample s[RTMI_MAX_SAMPLES_PER_LAUNCH];
 	uint32_t n, items_per_sample;
+	FastDiv d_items_per_sample;
 };
 
 RTMI_TRAVERSAL_KERNEL void k_primary_closest_samples(SceneDev S, int *__restrict__ counter, uint32_t n_items, rtmi_camera cam,
@@ -237,13 +253,12 @@ RTMI_TRAVERSAL_KERNEL void k_primary_closest_samples(SceneDev S, int *__restrict
 	for (uint32_t k = 0; k < RTMI_MAX_SAMPLES_PER_LAUNCH; ++k) // uniform index into the argument, one lane stores
 		if (threadIdx.x == k && k < set.n) table[k] = set.s[k];
 	__syncthreads();
-	const uint32_t per_block = g.blk_w * g.blk_h;
 	auto pixel = [&](uint32_t idx, uint32_t &smp, uint32_t &i, uint32_t &j) {
-		smp = idx / set.items_per_sample;
+		smp = fdiv(idx, set.d_items_per_sample);
 		const uint32_t k = idx - smp * set.items_per_sample;
 		PrimaryGrid gs = g;
 		gs.tile_first = table[smp].tile_first;
-		return primary_pixel(gs, cam, k / per_block, k % per_block, i, j);
+		return primary_pixel(gs, cam, k, i, j);
 	};
 	auto fetch = [&](uint32_t idx, RayD &R) {
 		uint32_t smp, i, j;
@@ -269,12 +284,11 @@ RTMI_TRAVERSAL_KERNEL void k_primary_closest_samples(SceneDev S, int *__restrict
 RTMI_TRAVERSAL_KERNEL void k_primary_work(SceneDev S, int *__restrict__ counter, uint32_t n_items, rtmi_camera cam, double sx,
                                                          double sy, PrimaryGrid g, Tune tune, unsigned long long *__restrict__ counts) {
 	extern __shared__ int stack[];
-	const uint32_t per_block = g.blk_w * g.blk_h;
 	const uint32_t lane = threadIdx.x & 63u;
 	Work w = {0u, 0u, 0u, 0u, 0u, 0u};
 	auto fetch = [&](uint32_t idx, RayD &R) {
 		uint32_t i, j;
-		if (!primary_pixel(g, cam, idx / per_block, idx % per_block, i, j)) return false;
+		if (!primary_pixel(g, cam, idx, i, j)) return false;
 		const D3 d = primary_dir(cam, i, j, sx, sy);
 		R.dx = d.x; R.dy = d.y; R.dz = d.z;
 		R.tmax = RTMI_INFINITY;
@@ -992,6 +1006,11 @@ static int64_t primary_grid(const rtmi_camera *cam, uint32_t tile_w, uint32_t ti
 	g.blk_h = std::min(std::max(8u, env_uint("RTMI_BLK_H", 32) / 8 * 8), (tile_h + 7) / 8 * 8);
 	g.blocks_x = (tile_w + g.blk_w - 1) / g.blk_w;
 	g.blocks_per_tile = g.blocks_x * ((tile_h + g.blk_h - 1) / g.blk_h);
+	g.d_per_block = make_fastdiv(g.blk_w * g.blk_h);
+	g.d_blocks_per_tile = make_fastdiv(g.blocks_per_tile);
+	g.d_tiles_x = make_fastdiv(g.tiles_x);
+	g.d_blocks_x = make_fastdiv(g.blocks_x);
+	g.d_sq_x = make_fastdiv(g.blk_w >> 3);
 	const uint64_t grid = local * g.blocks_per_tile;
 	if (grid > 0x7fffffffull) return fail(std::string(who) + ": grid too large");
 	return (int64_t)grid;
@@ -1007,7 +1026,7 @@ int rtmi_primary_closest_hit_dev(rtmi_scene *s, const rtmi_camera *cam, double s
 	const int64_t grid = primary_grid(cam, tile_w, tile_h, tile_first, tile_stride, g, who);
 	if (grid <= 0) return (int)grid;
 	const uint64_t n_items = (uint64_t)grid * g.blk_w * g.blk_h;
-	if (n_items > 0xff000000ull) return fail(std::string(who) + ": too many pixels for one launch");
+	if (n_items > 0x7fffffffull) return fail(std::string(who) + ": too many pixels for one launch"); // (item indices below 2^31: FastDiv)
 	int *slot = queue_slot(s, (hipStream_t)stream, who);
 	if (!slot) return -1;
 	const uint32_t pgrid = persistent_grid(s, k_primary_closest, n_items);
@@ -1038,9 +1057,10 @@ int rtmi_primary_closest_hit_samples_dev(rtmi_scene *s, const rtmi_camera *cam, 
 	const int64_t grid = primary_grid(cam, tile_w, tile_h, lowest, tile_stride, g, who);
 	if (grid <= 0) return (int)grid;
 	const uint64_t per_sample = (uint64_t)grid * g.blk_w * g.blk_h, n_items = per_sample * n_samples;
-	if (n_items > 0xff000000ull) return fail(std::string(who) + ": too many pixels for one launch");
+	if (n_items > 0x7fffffffull) return fail(std::string(who) + ": too many pixels for one launch"); // (item indices below 2^31: FastDiv)
 	set.n = n_samples;
 	set.items_per_sample = (uint32_t)per_sample;
+	set.d_items_per_sample = make_fastdiv((uint32_t)per_sample);
 	int *slot = queue_slot(s, (hipStream_t)stream, who);
 	if (!slot) return -1;
 	const uint32_t pgrid = persistent_grid(s, k_primary_closest_samples, n_items);
@@ -1057,7 +1077,7 @@ int rtmi_primary_work_dev(rtmi_scene *s, const rtmi_camera *cam, double sx, doub
 	const int64_t grid = primary_grid(cam, 64, 64, 0, 1, g, who);
 	if (grid <= 0) return (int)grid;
 	const uint64_t n_items = (uint64_t)grid * g.blk_w * g.blk_h;
-	if (n_items > 0xff000000ull) return fail(std::string(who) + ": too many pixels for one launch");
+	if (n_items > 0x7fffffffull) return fail(std::string(who) + ": too many pixels for one launch"); // (item indices below 2^31: FastDiv)
 	int *slot = queue_slot(s, (hipStream_t)stream, who);
 	if (!slot) return -1;
 	const uint32_t pgrid = persistent_grid(s, k_primary_work, n_items);
