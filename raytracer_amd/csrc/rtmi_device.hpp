@@ -638,9 +638,9 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 				const uint32_t nidle = (uint32_t)__popcll(idle);
 				if (nidle > 0) {
 					guard = 0; // the budget is per ray: a wave that keeps starting new rays keeps going
-					// Items come from the wave's own range [w_next, w_end); when that runs short the wave takes the
-					// next kQueueChunk items from the launch's counter (one atomic per chunk, not per refill: thousands
-					// of waves adding to one address was measured to serialise).
+					// Items come from the wave's own range [w_next, w_end); when that runs short the wave takes more from the
+					// range its workgroup shares, and when that is empty a whole claim from the launch's counter (one atomic
+					// per claim, not per refill: thousands of waves adding to one address was measured to serialise).
 					const uint32_t left = w_end - w_next;
 					uint32_t fresh = 0, fresh_end = 0;
 					bool got = false;
@@ -662,8 +662,8 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 							// the time since then, 100 MHz clock) and sizes its claims so that all resident workgroups claiming at its pace
 							// keep the counter busy a quarter of the time at most: the power of two nearest to rate x gridDim.x x 32 ns,
 							// between 64 and max_chunk.  (Doubling / halving on the last interval alone wandered up to the cap: measured.)
-							// That lands cheap rays (short any-hit rays: 33 M in a millisecond) on 1024-item claims and the soup's primary
-							// rays on 128.  Towards the end of the queue the size follows what is left: half an even share per workgroup,
+							// That lands cheap rays (short any-hit rays: 33 M in a millisecond) on the cap (512: larger claims gained there and
+							// lost on the frames' smaller launches, profiles/ab_r03.md) and the soup's primary rays on 128.  Towards the end of the queue the size follows what is left: half an even share per workgroup,
 							// but not below a quarter of the paced size (the last claims may crowd the counter, briefly).
 							if (lane == leader) {
 								for (;;) {

@@ -363,10 +363,10 @@ Tune refill_threshold() { // the tuning environment is read once
 	return t;
 }
 
-// Claim sizes a launch starts with (trace_queue adapts them to what its rays cost): kQueueChunk items per atomic, fewer
-// when the launch is so small that this would hand every resident wave its whole share in one or two claims (a launch
-// cannot end before its slowest wave has; smaller first claims leave something to balance with).  tail_chunk is the floor
-// of the end-game halving.
+// Claim sizes a launch STARTS with (trace_queue then sizes its claims from the rate at which its workgroups use items, between
+// 64 and max_chunk, and from what is left of the queue): kQueueChunk items per atomic, half of that when the launch is so small
+// that this would hand every resident wave its whole share in one or two claims (a launch cannot end before its slowest wave
+// has; smaller first claims leave something to balance with).  tail_chunk is the floor of the last claims.
 Tune launch_tune(Tune t, uint32_t grid, uint64_t n_items) {
 	static const unsigned fixed = env_uint("RTMI_CHUNK", 0);
 	if (fixed) { t.chunk = fixed; t.tail_chunk = std::max(16u, fixed / 2u); t.max_chunk = fixed; return t; }
