@@ -66,6 +66,10 @@ constexpr int kLeaf = INT32_MIN + 1;      // lane state: working through the tri
 #ifndef RTMI_POOL
 #define RTMI_POOL 1
 #endif
+#ifndef RTMI_TAIL_SHIFT
+#define RTMI_TAIL_SHIFT 2
+#endif
+constexpr uint32_t kTailShift = RTMI_TAIL_SHIFT; // the last claims of a launch are no smaller than the paced size >> this
 #ifndef RTMI_POOL_TAKE
 #define RTMI_POOL_TAKE 64
 #endif
@@ -690,7 +694,7 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 									}
 									const uint32_t seen_wg = *pool_seen;
 									const uint32_t rem = seen_wg < n_items ? n_items - seen_wg : 0u;
-									const uint32_t chunk = min(cc, max(max(32u, cc >> 2), rem / (2u * gridDim.x)));
+									const uint32_t chunk = min(cc, max(max(32u, cc >> kTailShift), rem / (2u * gridDim.x)));
 									const uint32_t base = (uint32_t)atomicAdd(counter, (int)chunk);
 									seen_now = base;
 									*pool_seen = base; // the other waves of the workgroup learn how far the queue has got
