@@ -881,6 +881,8 @@ int rtmi_radiosity_vertex_values(const double *verts, uint32_t n, const double *
 	const char *who = "rtmi_radiosity_vertex_values";
 	if (n == 0) return 0;
 	if (!verts || !B || !out) return fail(std::string(who) + ": NULL argument");
+	for (size_t k = 0; k < 9 * (size_t)n; ++k)
+		if (!std::isfinite(verts[k])) return fail(std::string(who) + ": non-finite vertex coordinate"); // (the corners are sorted by position)
 	try {
 		std::vector<double> centre(3 * (size_t)n);
 		for (uint32_t e = 0; e < n; ++e) center_of_triangle(verts + 9 * (size_t)e, centre.data() + 3 * (size_t)e);

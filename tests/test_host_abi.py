@@ -259,6 +259,9 @@ def test_vertex_values_equal_the_oracles_scan(oracle):
     assert np.array_equal(rt.api.vertex_values(lonely, [2.0, 3.0]), [[2, 2, 2], [3, 3, 3]])       # nobody shares a vertex: B_e
     assert rt.lib.rtmi_radiosity_vertex_values(None, 0, None, None) == 0
     assert rt.lib.rtmi_radiosity_vertex_values(None, 3, None, None) == -1 and b"NULL" in rt.lib.rtmi_last_error()
+    bad = lonely.copy(); bad[1, 4] = np.nan
+    with pytest.raises(rt.RtmiError, match="non-finite"):
+        rt.api.vertex_values(bad, [2.0, 3.0])
 
 
 def test_header_is_plain_c(tmp_path):
