@@ -698,6 +698,45 @@ def main():
         frame["studio_1080p"] = {"workload": "workloads.studio(64): %d triangles, 6 materials (Phong, microfacet, mirror, 2 refracting), 2 lights, 1920x1080, 10 AO rays" % len(vs),
                                  "depth1_ms": round(ms2, 3), "depth1_Mpixels_per_s": round(1920 * 1080 / ms2 / 1e3, 1),
                                  "depth3_ms": round(ms3, 3)}
+        # C4 (BASELINE config 4): ~100 K-triangle room, 1920x1080, primary closest hit, then per pixel 16 ambient-occlusion rays
+        # (radius 2, any hit), 1 hard-shadow ray (any hit) and — for a quarter of the frame — 100 soft-shadow rays (closest hit),
+        # every secondary ray built inside the query kernel (rtmi_ao_occlusion_dev, rtmi_shadow_occlusion_dev, rtmi_soft_shadow_dev)
+        room, rn, light4 = W.closed_box(91)
+        inner, inn, _ = W.closed_box(6, side=2.0)
+        inner = inner + np.tile([4.0, 4.0, 0.0], 3)[None, :]
+        tr4 = np.concatenate([room, inner])
+        nr4 = torch.from_numpy(np.ascontiguousarray(np.concatenate([rn, -inn]))).cuda()
+        sc4 = rt.Scene(tr4)
+        cam4 = rt.Camera.from_cam14(np.array([1.0, 1.0, 5.0, 6.0, 6.0, 1.0, 0, 0, 1, 1.0, -1.0, 1.0, -0.5625, 0.5625]), (1920, 1080))
+        n4, spp4, np4 = cam4.x_res * cam4.y_res, 16, 100
+        m4 = n4 // 4
+        rays4 = torch.zeros(n4 * 64, dtype=torch.uint8, device="cuda")
+        hits4 = torch.zeros(n4 * 24, dtype=torch.uint8, device="cuda")
+        occ4 = torch.zeros(n4 * spp4, dtype=torch.uint8, device="cuda")
+        socc4 = torch.zeros(n4, dtype=torch.uint8, device="cuda")
+        contrib4 = torch.zeros(m4 * np4, dtype=torch.uint8, device="cuda")
+        fac4 = torch.zeros(m4, dtype=torch.float64, device="cuda")
+        rt.primary_rays_dev(cam4, rays4.data_ptr(), stream=stream)
+        stages = (("primary_ms", n4, lambda: sc4.primary_dev(cam4, hits4.data_ptr(), stream=stream)),
+                  ("ao_16spp_ms", n4 * spp4, lambda: sc4.ao_occlusion_dev(nr4.data_ptr(), rays4.data_ptr(), hits4.data_ptr(), n4, spp4, 2.0, 1, occ4.data_ptr(), stream)),
+                  ("hard_shadow_ms", n4, lambda: sc4.shadow_occlusion_dev(nr4.data_ptr(), rays4.data_ptr(), hits4.data_ptr(), n4, light4, socc4.data_ptr(), stream)),
+                  ("soft_shadow_100_rays_quarter_frame_ms", m4 * np4, lambda: sc4.soft_shadow_dev(nr4.data_ptr(), rays4.data_ptr(), hits4.data_ptr(), m4, light4, np4, contrib4.data_ptr(), fac4.data_ptr(), stream)))
+        c4 = {"workload": "C4: closed room + inner box, %d triangles, 1920x1080: primary closest hit, 16 AO rays (radius 2) + 1 hard-shadow ray per pixel (any hit), 100 soft-shadow rays for a quarter of the pixels (closest hit); secondary rays built inside the query kernels" % len(tr4)}
+        a4, b4 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for name, n_rays, call in stages:
+            call()
+            torch.cuda.synchronize()
+            a4.record()
+            for _ in range(5):
+                call()
+            b4.record()
+            torch.cuda.synchronize()
+            ms = a4.elapsed_time(b4) / 5
+            c4[name] = round(ms, 3)
+            c4[name.replace("_ms", "_Mrays_per_s")] = round(n_rays / ms / 1e3, 1)
+        c4["frame_primary_ao_hard_shadow_ms"] = round(c4["primary_ms"] + c4["ao_16spp_ms"] + c4["hard_shadow_ms"], 3)
+        c4["frame_Mrays_per_s"] = round(n4 * (spp4 + 2) / c4["frame_primary_ao_hard_shadow_ms"] / 1e3, 1)
+        frame["c4_room"] = c4
 
     if rank == 0:
         line = {
