@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--res", default="3840x2160")
     ap.add_argument("--patches", type=int, default=65536)
     ap.add_argument("--ff-rows", type=int, default=-1, help="-1: build the whole 64K-patch form-factor matrix and solve on it; K>0: a sample of K rows; 0: skip")
+    ap.add_argument("--ff-launch-rows", type=int, default=0, help="rows per rtmi_form_factors_dev call of the build; 0 (default): this rank's whole block in ONE call")
     ap.add_argument("--no-solver", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-tiles", action="store_true", help="skip the tile_launch section (profiling runs: its launches would mix into the per-kernel averages)")
@@ -356,7 +357,8 @@ def main():
         torch.cuda.empty_cache()
 
         # (c) form factors at 64 K patches: box with 12·74² − (ceiling opening) patches, light above the opening.
-        #     --ff-rows -1 (default): this rank's whole row block, in launches of 4096 rows, then the solve on that
+        #     --ff-rows -1 (default): this rank's whole row block in ONE call (--ff-launch-rows K: in calls of K rows; one launch of
+        #     the whole block runs 15 % faster than launches of 4096 rows, profiles/ab_r03.md), then the solve on that
         #     real F; --ff-rows K > 0: a sample of K rows only (extrapolated, marked as such).
         if args.ff_rows != 0:
             k = max(1, int(round((n / 12.0) ** 0.5)))
@@ -396,13 +398,14 @@ def main():
             n_launch = 0
             t0 = time.perf_counter()
             fe0.record()
-            for first in range(0, nr_s, 4096):
-                build(first, min(4096, nr_s - first))
+            lrows = nr_s if args.ff_launch_rows <= 0 else min(args.ff_launch_rows, nr_s)
+            for first in range(0, nr_s, lrows):
+                build(first, min(lrows, nr_s - first))
                 n_launch += 1
             fe1.record()
             barrier()
             ff_s = max_over_ranks(time.perf_counter() - t0)
-            ff_kernel_ms = fe0.elapsed_time(fe1) / n_launch      # k_form_factors (+ the light column's 4096 rays) per launch, HIP events
+            ff_kernel_ms = fe0.elapsed_time(fe1) / n_launch      # k_form_factors (+ the light column's rays) per launch, HIP events
             box.check()
             ne = rad.numOfElements
             vis_rays = 10.0 * (ne - 1) * (nb - 1 if full else nr_s * world)
@@ -410,12 +413,12 @@ def main():
             # (a box: pairs on different walls); counted on the host from the normals
             _, inv, cnt = np.unique(np.round(normals, 9), axis=0, return_inverse=True, return_counts=True)
             shoot = 1.0 - float((cnt.astype(np.float64) ** 2).sum()) / float(ne) ** 2
-            pairs_launch = 10.0 * (ne - 1) * min(4096, nr_s)
+            pairs_launch = 10.0 * (ne - 1) * nr_s / n_launch
             ff_tflops = (FLOP_FF_SAMPLE + FLOP_FF_RAY * shoot) * pairs_launch / (ff_kernel_ms * 1e-3) / 1e12
             roofline_formfactor = {
                 "kernel": "k_form_factors", "bound": "valu (fp64 vector)", "achieved": round(ff_tflops, 3), "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s fp64 (algorithmic: %.0f flop per sample + %.0f per ray shot; divisions and roots count 1)" % (FLOP_FF_SAMPLE, FLOP_FF_RAY),
-                "frac": round(ff_tflops / FP64_PEAK_TFLOPS, 4), "kernel_ms": round(ff_kernel_ms, 3), "rows_per_launch": min(4096, nr_s),
+                "frac": round(ff_tflops / FP64_PEAK_TFLOPS, 4), "kernel_ms": round(ff_kernel_ms, 3), "rows_per_launch": lrows,
                 "pair_samples_per_launch": pairs_launch, "rays_shot_fraction": round(shoot, 4),
                 "G_pair_samples_per_s": round(pairs_launch / (ff_kernel_ms * 1e-3) / 1e9, 2), "traffic": None}
             tr = os.path.join(ROOT, "profiles", "traffic.json")
@@ -426,8 +429,9 @@ def main():
                                 "valu_instructions_per_pair_sample", "scratch_bytes", "vgprs"):
                         if key in tj:
                             roofline_formfactor[key] = tj[key]
-                    if "hbm_bytes_per_launch" in tj and tj.get("rows_per_launch") == min(4096, nr_s):
-                        roofline_formfactor["traffic"] = tj["hbm_bytes_per_launch"]
+                    if "hbm_bytes_per_launch" in tj and tj.get("rows_per_launch"):   # per launch of THIS size: the stored bytes scale with the rows
+                        roofline_formfactor["traffic"] = tj["hbm_bytes_per_launch"] * lrows / tj["rows_per_launch"]
+                        roofline_formfactor["traffic_note"] = "scaled from a %d-row launch (bytes per matrix entry do not depend on the launch size)" % tj["rows_per_launch"]
                     if tj:
                         roofline_formfactor["pmc_source"] = "stored: profiles/%s" % tj.get("source", "?")
                 except Exception:

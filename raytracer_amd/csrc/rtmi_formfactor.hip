@@ -252,6 +252,9 @@ RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx
 #ifndef RTMI_FF_SAME_PLANE
 #define RTMI_FF_SAME_PLANE 1
 #endif
+#ifndef RTMI_FF_XCD_BLOCK
+#define RTMI_FF_XCD_BLOCK 1
+#endif
 // Workgroup = ONE group of 64 patches j (blockIdx.x); its four waves take four consecutive bands of rows i, so the group's
 // per-lane tables are fetched once per workgroup and shared through the L1.  Columns j < n_patches only; the light's row
 // (i == n_patches) is zero (:391-393), the diagonal too (:382).
@@ -271,9 +274,18 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 	// Workgroups are dealt to the 8 XCDs round-robin (linear id mod 8), each with its own L2.  Groups that are neighbours in
 	// depth-first order fill the same 128-byte lines of a row of F (their patch ids interleave), so XCD x takes the x-th
 	// contiguous eighth of the groups: the partial lines of neighbouring groups meet in ONE L2 and leave it merged.
+#if RTMI_FF_XCD_BLOCK
+	// ... in BLOCKS of RTMI_FF_XCD_BLOCK groups dealt to the XCDs in turn (block b to XCD b mod 8): neighbouring groups of a block
+	// still meet in one L2, and every XCD gets an even mix of the scene — with one contiguous eighth per XCD (round 2) a launch
+	// whose rows lie in one wall left the XCD that owned that wall's columns (all zeros, no work) idle: 4096-row launches ran at
+	// 85 G pair-samples/s where one launch of the whole matrix, balanced by symmetry, ran at 114 (profiles/ab_r03.md).
+	const uint32_t xl = blockIdx.x >> 3;
+	const uint32_t g = ((xl / RTMI_FF_XCD_BLOCK) * 8u + (blockIdx.x & 7u)) * RTMI_FF_XCD_BLOCK + (xl % RTMI_FF_XCD_BLOCK);
+#else
 	const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
 	const uint32_t g = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-	if (g >= n_groups) return; // the padded tail of the last eighth
+#endif
+	if (g >= n_groups) return; // the padded tail
 	const uint32_t band = blockIdx.y * (kBlock / 64u) + uniform_u32(threadIdx.x >> 6);
 	const uint32_t r_begin = band * band_rows, r_end = min(n_rows, r_begin + band_rows);
 	if (r_begin >= n_rows) return; // whole wave
@@ -897,7 +909,12 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		// beam margin: the 1e-5 origin offset, the exact test's per-ray pad (<= 2^-17·absmax) and the fp32 roundings of both
 		const float margin = 1.52587890625e-05f * s->dev.absmax + 1e-4f;
 		const uint32_t n_bands = (count + band - 1) / band;
+#if RTMI_FF_XCD_BLOCK
+		const uint32_t xcd_blocks = (P->n_groups + RTMI_FF_XCD_BLOCK - 1u) / RTMI_FF_XCD_BLOCK; // blocks of groups, dealt to the 8 XCDs in turn
+		const dim3 grid((xcd_blocks + 7u) / 8u * RTMI_FF_XCD_BLOCK * 8u, (n_bands + kBlock / 64 - 1) / (kBlock / 64));
+#else
 		const dim3 grid((P->n_groups + 7u) / 8u * 8u, (n_bands + kBlock / 64 - 1) / (kBlock / 64));
+#endif
 		// a lane's stack: up to pend_cap sibling subtrees waiting (more is rare: that ray starts over from the root) + the
 		// depth + 1 entries the traversal inside one of them can need
 		const uint32_t pend_cap = std::min(s->info.max_depth + 1u, std::max(1u, env_uint("RTMI_FF_PEND", 8)));

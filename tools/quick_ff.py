@@ -8,13 +8,14 @@ from raytracer_amd import workloads
 torch.cuda.set_device(0)
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 74
+row0 = int(os.environ.get("ROW0", "1000"))
 verts, normals, light = workloads.closed_box(k)
 box = rt.Scene(verts)
 rad = rt.Radiosity(box, normals, light)
-rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=1000, n_rows=1024)   # warm-up; the library times its two kernels here
+rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=row0, n_rows=1024)   # warm-up; the library times its two kernels here
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-F = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=1000, n_rows=rows)
+F = rad.findFormFactor(samples=10, light_samples=30, seed=1, row0=row0, n_rows=rows)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 dig = hashlib.sha1(F.cpu().numpy().tobytes()).hexdigest()[:12]
