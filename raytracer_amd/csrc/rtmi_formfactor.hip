@@ -398,29 +398,36 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 			const uint32_t mask_j = pair ? ((behind_j & bits_above(lca)) | front_j) : 0u;
 			// what the WAVE loops over per sample (supersets of the lanes' own bits, which are tested per lane below)
 			const uint32_t um_i_all = behind_i | um_i_front, um_j_all = (behind_shared & bits_above(lca0)) | um_j_front;
+#ifdef RTMI_FF_COUNT
+			{ // lanes whose pair keeps a sibling for its rays ("dirty"): how many per wave and row
+				const uint32_t nd = (uint32_t)__popcll(__ballot(pair && (front_i | front_j) != 0u));
+				FF_COUNT(83, 1); FF_COUNT(84, nd ? 1 : 0); FF_COUNT(85, nd);
+				FF_COUNT(86, nd >= 1 && nd <= 6 ? 1 : 0); FF_COUNT(87, nd >= 7 && nd <= 12 ? 1 : 0); FF_COUNT(88, nd >= 13 && nd <= 25 ? 1 : 0); FF_COUNT(89, nd > 25 ? 1 : 0);
+			}
+#endif
 			// ---- the samples of the pair, in the reference's order (:309-330) --------------------------------------
 			const uint64_t h0 = mix64(seed ^ (((uint64_t)i << 32) | jj));
 			double ff = 0.0;
 			for (uint32_t k = 0; k < samples; ++k) {
-				bool shoot = false;
-				D3 xj = d3(0, 0, 0), dir = d3(0, 0, 1), org = d3(0, 0, 0);
-				double c1 = 0.0, c2 = 0.0, dist2 = 0.0;
-				double bmin_j = 0.0;
-				if (pair) {
-					const D3 xi = sample_point_h(ei, h0, k, 0);
-					xj = sample_point_hb(ejp, h0, k, 1, bmin_j);
-					// Unit(xj − xi) once: the reference evaluates it three times (:235, :317, and Unit(xi − xj) = its exact
-					// negation, :318), and dist2 = (xi−xj)·(xi−xj) is the squared length inside it — same IEEE operations.
-					const D3 vec = xj - xi;
-					dist2 = len2(vec);
-					dir = dist2 > 0.0 ? vec / sqrt(dist2) : d3(0, 0, 0);
-					// A sample adds to the sum only if delF > 0, i.e. both cosines are positive (:320-324) — whatever the
-					// visibility ray says.  So the ray is shot only for those samples.
-					c1 = dot(dir, ni);
-					c2 = -dot(dir, nj);
-					org = xi + (kEpsilon * dir);
-					shoot = c1 > 0.0 && c2 > 0.0;
-				}
+				// Every lane evaluates its sample, pair or not (the diagonal lane and the padded tail read patch jj like any other and
+				// are masked by `pair`): no branch around the arithmetic, and no values to preset for the lanes that would skip it.
+				const D3 xi = sample_point_h(ei, h0, k, 0);
+				double bmin_j;
+				const D3 xj = sample_point_hb(ejp, h0, k, 1, bmin_j);
+				// Unit(xj − xi) once: the reference evaluates it three times (:235, :317, and Unit(xi − xj) = its exact
+				// negation, :318), and dist2 = (xi−xj)·(xi−xj) is the squared length inside it — same IEEE operations.
+				const D3 vec = xj - xi;
+				const double dist2 = len2(vec);
+				// (The reference's Unit() returns 0 for a zero vector, vec3.h:98-101.  Here xj == xi gives 0/0: every component a
+				// NaN, both cosines NaNs, `shoot` false — what the zero vector gives (cosines ±0), without the branch around the
+				// root and the division.  A NaN direction is never used: everything below is under `shoot` or one of its subsets.)
+				const D3 dir = vec / sqrt(dist2);
+				// A sample adds to the sum only if delF > 0, i.e. both cosines are positive (:320-324) — whatever the
+				// visibility ray says.  So the ray is shot only for those samples.
+				const double c1 = dot(dir, ni);
+				const double c2 = -dot(dir, nj);
+				const D3 org = xi + (kEpsilon * dir);
+				const bool shoot = pair & (c1 > 0.0) & (c2 > 0.0);
 				FF_COUNT(0, 1);
 				if (__ballot(shoot) == 0ull) continue;
 				FF_COUNT(13, 1); FF_COUNT_LANES(9, shoot);
@@ -443,9 +450,13 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				// keeps |det| out of the ±1e-8 window (and is >= graze_cos_j); dist² > 1e-6 keeps t = dist − 1e-5 (error below
 				// 1e-3·sure_margin/c2 < 3.4e-4) positive.  Flat, geometric-normal patches only (planes_on, as for the flags).
 				{
-					const bool sure = planes_on != 0u && !graze_i && c2 > sure_cos && bmin_j * c2 > sure_margin && dist2 > 1e-6 &&
-					                  front_i == 0u && front_j == 0u && !(S.absmax > 1e4f);
+					const bool sure = (planes_on != 0u) & !graze_i & (c2 > sure_cos) & (bmin_j * c2 > sure_margin) & (dist2 > 1e-6) &
+					                  (front_i == 0u) & (front_j == 0u) & !(S.absmax > 1e4f); // (plain ANDs: no branch, no phi behind the vote)
+#ifdef RTMI_FF_TIMING_ALL_SURE // timing experiment only (wrong results wherever something is in the way): every sample takes the certain path
+					if (true) {
+#else
 					if (__ballot(shoot && !sure) == 0ull) {
+#endif
 						FF_COUNT(79, 1);
 						if (shoot) {
 							const double cosFactor = c1 * c2;

@@ -64,17 +64,25 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 // (h0 = mix64(seed ^ (a << 32 | b)) is the same for every sample of a pair: callers may hoist it)
 // ONE hash per point (round 3; two before): its upper 32 bits give u, its lower 32 bits v, each on a grid of 2^-32 — exact in
 // double, one conversion instruction each instead of the four a 53-bit integer takes, and half the 64-bit multiplies (a
-// 64-bit multiply is four quarter-rate 32-bit ones on gfx950).  The reference draws both from an unseeded mt19937
+// 64-bit multiply is three 32-bit multiplies and an add3; they issue at the rate of other vector instructions on gfx950).  The reference draws both from an unseeded mt19937
 // (util.cpp:96-124); the generator is ours; the CPU checker restates it, and
 // tests/test_oracle_golden.py checks the stream's uniformity.
 // bmin: the smallest of the point's three barycentric weights (exact: u, v and w = 1 − u − v are multiples of 2^-32)
 __device__ __forceinline__ D3 sample_point_hb(const double *__restrict__ e, uint64_t h0, uint32_t k, uint32_t which, double &bmin) {
 	const uint64_t h = mix64(h0 ^ (((uint64_t)k << 32) | which));
-	double u = (double)(uint32_t)(h >> 32) * 0x1.0p-32;
+	uint32_t hi = (uint32_t)(h >> 32);
+	// (seen as a 64-bit integer with a zero upper half, the conversion becomes cvt(0)·2^32 + cvt(hi): an addition of 0.0 the
+	// compiler may not fold; behind this it is one v_cvt_f64_u32)
+	asm volatile("" : "+v"(hi));
+	double u = (double)hi * 0x1.0p-32;
 	double v = (double)(uint32_t)h * 0x1.0p-32;
 	if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
 	const double w = 1.0 - u - v;
-	bmin = fmin(fmin(u, v), w);
+	// fmin() first canonicalises operands that come out of a select (v_max_f64 x, x — for signalling NaNs); none of the three
+	// can be a NaN, so the bare instruction gives the same value
+	double m;
+	asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(u), "v"(v));
+	asm("v_min_f64 %0, %1, %2" : "=v"(bmin) : "v"(m), "v"(w));
 	return d3((w * e[0]) + (u * e[3]) + (v * e[6]), (w * e[1]) + (u * e[4]) + (v * e[7]),
 	          (w * e[2]) + (u * e[5]) + (v * e[8]));
 }

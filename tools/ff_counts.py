@@ -42,3 +42,5 @@ print("sibling boxes hit by a ray, by level (lane count): path i", [int(x) for x
 print("                                                   path j", [int(x) for x in c[48:72]])
 print("trace_from calls with a grazing lane in the wave %d (grazing lanes entering %d, all lanes entering %d); node steps without / with a grazing lane %d / %d, leaf steps %d / %d" % (
     c[72], c[73], c[78], c[74], c[75], c[76], c[77]))
+print("wave-rows %d; with a lane that keeps a sibling for its rays %d (%.3f); such lanes per wave-row with any %.1f; wave-rows with 1-6 / 7-12 / 13-25 / more such lanes: %d / %d / %d / %d" % (
+    c[83], c[84], c[84] / max(1, c[83]), c[85] / max(1, c[84]), c[86], c[87], c[88], c[89]))
