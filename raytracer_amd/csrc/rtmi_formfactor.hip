@@ -252,6 +252,13 @@ RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx
 #ifndef RTMI_FF_SAME_PLANE
 #define RTMI_FF_SAME_PLANE 1
 #endif
+#ifndef RTMI_FF_REGROUP
+#define RTMI_FF_REGROUP 1
+#endif
+#ifndef RTMI_FF_REGROUP_NUM // samples are dealt over the wave when that takes at most NUM/DEN as many passes as there are samples
+#define RTMI_FF_REGROUP_NUM 1
+#define RTMI_FF_REGROUP_DEN 2
+#endif
 #ifndef RTMI_FF_XCD_BLOCK
 #define RTMI_FF_XCD_BLOCK 1
 #endif
@@ -292,25 +299,35 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 	const uint32_t j0 = T.dfs[(size_t)g * 64u]; // a group's first slot is always a patch
 	const uint32_t j = T.dfs[(size_t)g * 64u + lane];
 	const bool valid_j = j != RTMI_MISS;
-	const uint32_t jj = valid_j ? j : j0;
-	const PatchMeta mj = T.meta[jj];
 	const PatchMeta m0 = T.meta[j0]; // wave-uniform
-	const uint32_t dj = meta_depth(mj), leaf_j = meta_leafpos(mj);
-	const double *ejp = P.verts + 9 * (size_t)jj;
-	const D3 nj = d3(P.normals[3 * (size_t)jj], P.normals[3 * (size_t)jj + 1], P.normals[3 * (size_t)jj + 2]);
-	const double area_j = P.area[jj];
-	const double area_term = area_j / (int)samples; // :319, the same for every sample
-	const ChainEntry *chain_j = T.chain + mj.chain_off;
+	// The patch a lane is evaluating: its own column — or, while the samples of the lanes that kept a sibling are dealt over the
+	// wave (below), another lane's.  Everything about it that the sample loop reads:
+	uint32_t jj, dj, leaf_j, behind_j;
+	PatchMeta mj;
+	const double *ejp;
+	D3 nj;
+	double area_term;
+	const ChainEntry *chain_j;
+	auto take_patch = [&](uint32_t jx) {
+		jj = jx;
+		mj = T.meta[jx];
+		dj = meta_depth(mj);
+		leaf_j = meta_leafpos(mj);
+		ejp = P.verts + 9 * (size_t)jx;
+		nj = d3(P.normals[3 * (size_t)jx], P.normals[3 * (size_t)jx + 1], P.normals[3 * (size_t)jx + 2]);
+		area_term = P.area[jx] / (int)samples; // :319, the same for every sample
+		chain_j = T.chain + mj.chain_off;
+		behind_j = mj.behind & bits_below(dj); // which levels hold a sibling behind j's plane is j's own affair (PatchMeta::behind)
+	};
+	take_patch(valid_j ? j : j0);
 	const ChainEntry *chain_0 = T.chain + m0.chain_off;
 	// The group's paths agree on their first `common` levels: those siblings are the same for every lane (read once per wave
 	// through the scalar cache, chain_0); below, each lane has its own.
 	const uint32_t pdiff = mj.path ^ m0.path;
 	const uint32_t common = wave_min_u32(min(dj, pdiff ? (uint32_t)(__ffs((int)pdiff) - 1) : 32u));
 	const uint32_t low = bits_below(common);
-	// Which levels of path j hold a sibling behind j's plane is j's own affair (PatchMeta::behind).  Of the shared levels, the
-	// wave needs: those SOME lane has to test against its beam (not behind that lane's plane), and those behind SOME lane's
-	// plane (a grazing ray tests them) — both the same for every row.
-	const uint32_t behind_j = mj.behind & bits_below(dj);
+	// Of the shared levels, the wave needs: those SOME lane has to test against its beam (not behind that lane's plane), and
+	// those behind SOME lane's plane (a grazing ray tests them) — both the same for every row.
 	const uint32_t cand_shared = wave_or_u32(~mj.behind & low), behind_shared = wave_or_u32(mj.behind & low);
 	// the group's two constants of the "certain hit" test below (host: build_ff_tables), wave-uniform
 	const uint4 gconst = t_gconst[g];
@@ -323,6 +340,9 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 	// zeros; tests compare.)
 	const uint32_t gkey = RTMI_FF_SAME_PLANE ? gconst.z : 0u;
 	const uint32_t *t_pkey = reinterpret_cast<const uint32_t *>(t_gconst + n_groups);
+	// dealing samples over the wave (below): lane L holds sample deal_k of the deal_q-th pair of a pass
+	const uint32_t deal_per_pass = RTMI_FF_REGROUP && samples <= 64u ? 64u / samples : 0u;
+	const uint32_t deal_m16 = uniform_u32((65536u + samples - 1u) / samples); // L div S = (L·m16) >> 16 for L < 64, S <= 64 (L·(m16·S − 2^16) < 2^16)
 	for (uint32_t r = r_begin; r < r_end; ++r) {
 		const uint32_t i = row0 + r; // wave-uniform
 		double out = 0.0;
@@ -394,8 +414,6 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 					}
 				}
 			}
-			const uint32_t mask_i = pair ? ((behind_i & ~(1u << lca)) | front_i) : 0u;
-			const uint32_t mask_j = pair ? ((behind_j & bits_above(lca)) | front_j) : 0u;
 			// what the WAVE loops over per sample (supersets of the lanes' own bits, which are tested per lane below)
 			const uint32_t um_i_all = behind_i | um_i_front, um_j_all = (behind_shared & bits_above(lca0)) | um_j_front;
 #ifdef RTMI_FF_COUNT
@@ -406,9 +424,49 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 			}
 #endif
 			// ---- the samples of the pair, in the reference's order (:309-330) --------------------------------------
-			const uint64_t h0 = mix64(seed ^ (((uint64_t)i << 32) | jj));
+			// Lanes whose pair kept a sibling in front of a plane ("dirty": front_i | front_j != 0 — the same for all samples of the
+			// pair) send EVERY sample down the long way: triangle j, the sibling boxes, perhaps a walk; and a wave takes the long
+			// way for a sample as soon as one of its lanes does.  On the 64 K box 30 % of the (wave, row)s have such lanes, a
+			// dozen of the 64 on average, and they cost the kernel two fifths of its time.  So those lanes sit out the sample loop
+			// (the others then take the certain-hit path every time), and afterwards THEIR samples are dealt over the wave:
+			// lane L takes sample L mod S of the (L div S)-th such pair — 64 div S pairs per pass, all their samples at once.
+			// The sums stay the reference's: a pair's terms reach its own lane through ds_bpermute and are added in sample order.
+			// Not worth it when the passes would be more than half as many as the samples (then every lane stays in the loop).
+			const bool dirty = RTMI_FF_REGROUP && pair && (front_i | front_j) != 0u;
+			const unsigned long long dmask = __ballot(dirty);
+			const uint32_t n_dirty = (uint32_t)__popcll(dmask);
+			const uint32_t passes_wanted = deal_per_pass ? (n_dirty + deal_per_pass - 1u) / deal_per_pass : 0u;
+			const uint32_t n_pass = passes_wanted * RTMI_FF_REGROUP_DEN <= samples * RTMI_FF_REGROUP_NUM ? passes_wanted : 0u;
+			const uint32_t my_rank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u)); // dirty lanes below this one
+			unsigned long long undealt = dmask;
+			// ---- the samples of the pair, in the reference's order (:309-330) --------------------------------------
+			uint64_t h0 = mix64(seed ^ (((uint64_t)i << 32) | jj));
+			uint32_t e_front_i = front_i, e_front_j = front_j, e_lca = lca; // of the pair the lane is evaluating
 			double ff = 0.0;
-			for (uint32_t k = 0; k < samples; ++k) {
+			for (uint32_t t = 0; t < samples + n_pass; ++t) {
+				uint32_t k = t;
+				bool act = pair && !(n_pass != 0u && dirty);
+				if (t >= samples) { // a pass over the dealt samples (wave-uniform branch)
+					FF_COUNT(90, 1);
+					const uint32_t deal_q = (lane * deal_m16) >> 16, deal_k = lane - deal_q * samples;
+					uint32_t src = 0u;
+					act = false;
+					for (uint32_t q = 0; q < deal_per_pass && undealt != 0ull; ++q) {
+						const uint32_t b = (uint32_t)__ffsll((long long)undealt) - 1u;
+						undealt &= undealt - 1ull;
+						if (deal_q == q) { src = b; act = true; }
+					}
+					const uint32_t jx = (uint32_t)__shfl((int)j, (int)src, 64);
+					e_front_i = (uint32_t)__shfl((int)front_i, (int)src, 64);
+					e_front_j = (uint32_t)__shfl((int)front_j, (int)src, 64);
+					take_patch(act ? jx : (valid_j ? j : j0)); // (a lane without a share evaluates its own column, masked)
+					const uint32_t x = mi.path ^ mj.path;
+					e_lca = x ? (uint32_t)(__ffs((int)x) - 1) : 0u;
+					h0 = mix64(seed ^ (((uint64_t)i << 32) | jj));
+					k = deal_k;
+				}
+				double add = 0.0; // what this sample adds to its pair's sum
+				do {
 				// Every lane evaluates its sample, pair or not (the diagonal lane and the padded tail read patch jj like any other and
 				// are masked by `pair`): no branch around the arithmetic, and no values to preset for the lanes that would skip it.
 				const D3 xi = sample_point_h(ei, h0, k, 0);
@@ -427,9 +485,9 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				const double c1 = dot(dir, ni);
 				const double c2 = -dot(dir, nj);
 				const D3 org = xi + (kEpsilon * dir);
-				const bool shoot = pair & (c1 > 0.0) & (c2 > 0.0);
+				const bool shoot = act & (c1 > 0.0) & (c2 > 0.0);
 				FF_COUNT(0, 1);
-				if (__ballot(shoot) == 0ull) continue;
+				if (__ballot(shoot) == 0ull) break;
 				FF_COUNT(13, 1); FF_COUNT_LANES(9, shoot);
 				// Triangle i lies 1e-5 BEHIND the origin along the ray (t = −1e-5 up to rounding of relative size 1e-15/c1): it
 				// cannot be hit unless the ray all but grazes it — then it is tested like any other, and so is everything
@@ -451,7 +509,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				// 1e-3·sure_margin/c2 < 3.4e-4) positive.  Flat, geometric-normal patches only (planes_on, as for the flags).
 				{
 					const bool sure = (planes_on != 0u) & !graze_i & (c2 > sure_cos) & (bmin_j * c2 > sure_margin) & (dist2 > 1e-6) &
-					                  (front_i == 0u) & (front_j == 0u) & !(S.absmax > 1e4f); // (plain ANDs: no branch, no phi behind the vote)
+					                  (e_front_i == 0u) & (e_front_j == 0u) & !(S.absmax > 1e4f); // (plain ANDs: no branch, no phi behind the vote)
 #ifdef RTMI_FF_TIMING_ALL_SURE // timing experiment only (wrong results wherever something is in the way): every sample takes the certain path
 					if (true) {
 #else
@@ -461,9 +519,9 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 						if (shoot) {
 							const double cosFactor = c1 * c2;
 							const double delF = cosFactor / ((kPi * dist2) + area_term);
-							if (delF > 0.0) ff += delF;
+							if (delF > 0.0) add = delF;
 						}
-						continue;
+						break;
 					}
 				}
 #endif
@@ -487,7 +545,10 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 					else from_root = true;
 				};
 				if (walk && (graze_i || S.absmax > 1e4f)) push((int)~(leaf_i << 3));
-				const uint32_t s_i = graze_i ? mask_i : front_i, s_j = graze_j ? mask_j : front_j;
+				// mask_i / mask_j: every sibling a grazing ray has to look at — those behind the plane as well (not the one the other
+				// patch lies in: level lca of path i; nor path j's above the parting)
+				const uint32_t s_i = graze_i ? ((behind_i & ~(1u << e_lca)) | e_front_i) : e_front_i;
+				const uint32_t s_j = graze_j ? ((behind_j & bits_above(e_lca)) | e_front_j) : e_front_j;
 				const bool any_graze_i = __ballot(walk && graze_i) != 0ull, any_graze_j = __ballot(walk && graze_j) != 0ull;
 				const bool any_graze = any_graze_i || any_graze_j; (void)any_graze;
 				const uint32_t um_i = any_graze_i ? um_i_all : um_i_front, um_j = any_graze_j ? um_j_all : um_j_front;
@@ -563,11 +624,30 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 					if (vis) {
 						const double cosFactor = c1 * c2;
 						const double delF = cosFactor / ((kPi * dist2) + area_term);
-						if (delF > 0.0) ff += delF;
+						if (delF > 0.0) add = delF;
+					}
+				}
+				} while (0);
+				if (t < samples) ff += add; // (a sum that starts at +0 and takes positive terms is never −0: adding +0 changes nothing)
+				else {
+					// the pass's terms go home: a dealt pair's samples sit in S consecutive lanes, its own lane adds them in order
+					const uint32_t first = my_rank - (t - samples) * deal_per_pass; // my pair's place in this pass, if it is in it
+					const bool mine = dirty && first < deal_per_pass;
+					for (uint32_t kk = 0; kk < samples; ++kk) {
+						const double term = shfl_f64(add, (mine ? first : 0u) * samples + kk);
+						if (mine) ff += term;
 					}
 				}
 			}
-			ff = ff / ((double)samples);
+			if (n_pass != 0u) { // back to the lane's own column (through an index the compiler cannot match with the first call's: the
+				// addresses it would otherwise keep over the whole kernel for this were spilled)
+				uint32_t jo = valid_j ? j : j0;
+				asm volatile("" : "+v"(jo));
+				take_patch(jo);
+			}
+			uint32_t ns = samples; // (converted here, per row: held as a double over the kernel it was spilled)
+			asm volatile("" : "+s"(ns));
+			ff = ff / ((double)ns);
 			// (area_j read again, through an index the compiler cannot match with line 269's: kept in registers over the row
 			// it was the one value the kernel spilled.)
 			uint32_t jr = jj;

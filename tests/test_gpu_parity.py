@@ -281,6 +281,29 @@ def test_form_factor_path_walk_equals_root_traversal_and_oracle(rt, oracle, monk
         assert np.array_equal(part, F_path[61:136])
 
 
+@pytest.mark.parametrize("samples", [1, 2, 3, 7, 10, 21, 33, 64, 65])
+def test_form_factor_samples_dealt_over_the_wave(rt, oracle, monkeypatch, samples):
+    """The path-walk kernel lets the lanes whose pair kept a sibling for its rays sit out the sample loop and deals THEIR
+    samples over the wave afterwards (lane L: sample L mod S of the (L div S)-th such pair), adding the terms back in sample
+    order.  Every S from one pair per pass (33, 64) to 32 (2), S = 1 and S > 64 (no dealing): the same F as the root
+    traversal, which has no such loop, bit for bit; rows equal the oracle's."""
+    from raytracer_amd import workloads
+    vb, nb, _ = workloads.closed_box(10)                             # 1200 patches: the bench's geometry, 19 groups
+    inner = workloads._box((3.0, 2.0, 0.0), (6.0, 5.5, 4.0), 3)
+    for verts, normals in ((vb, nb), (np.concatenate([vb, inner]), np.concatenate([nb, workloads.face_normals(inner)]))):
+        n = len(verts)
+        rad = rt.Radiosity(rt.Scene(verts), normals, None)
+        monkeypatch.setenv("RTMI_FF_KERNEL", "path")
+        F_path = rad.findFormFactor(samples=samples, seed=5).cpu().numpy()[:, :n]
+        monkeypatch.setenv("RTMI_FF_KERNEL", "flat")
+        F_flat = rad.findFormFactor(samples=samples, seed=5).cpu().numpy()[:, :n]
+        monkeypatch.setenv("RTMI_FF_KERNEL", "path")
+        assert np.array_equal(F_path.view(np.uint32), F_flat.view(np.uint32))
+        for r in (3, n - 2):
+            want = oracle.form_factors(verts, normals, samples, 5, row0=r, n_rows=1)[0].astype(np.float32)
+            assert np.array_equal(F_path[r], want)
+
+
 def _multi_plane_scenes():
     """Face-normal geometry (so the host's plane flags are ON) whose 64-patch groups of the form-factor kernel span
     several planes and have occluders that lie behind one patch's plane and in front of its group mates': a staircase

@@ -44,3 +44,4 @@ print("trace_from calls with a grazing lane in the wave %d (grazing lanes enteri
     c[72], c[73], c[78], c[74], c[75], c[76], c[77]))
 print("wave-rows %d; with a lane that keeps a sibling for its rays %d (%.3f); such lanes per wave-row with any %.1f; wave-rows with 1-6 / 7-12 / 13-25 / more such lanes: %d / %d / %d / %d" % (
     c[83], c[84], c[84] / max(1, c[83]), c[85] / max(1, c[84]), c[86], c[87], c[88], c[89]))
+print("passes over dealt samples %d (%.2f per wave-row with such lanes)" % (c[90], c[90] / max(1, c[84])))
