@@ -432,7 +432,8 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 			// lane L takes sample L mod S of the (L div S)-th such pair — 64 div S pairs per pass, all their samples at once.
 			// The sums stay the reference's: a pair's terms reach its own lane through ds_bpermute and are added in sample order.
 			// Not worth it when the passes would be more than half as many as the samples (then every lane stays in the loop).
-			const bool dirty = RTMI_FF_REGROUP && pair && (front_i | front_j) != 0u;
+			// (Only where the other lanes can take the certain path at all: flat patches with geometric normals, coordinates below 1e4.)
+			const bool dirty = RTMI_FF_REGROUP && RTMI_FF_SKIP_MT && planes_on != 0u && !(S.absmax > 1e4f) && pair && (front_i | front_j) != 0u;
 			const unsigned long long dmask = __ballot(dirty);
 			const uint32_t n_dirty = (uint32_t)__popcll(dmask);
 			const uint32_t passes_wanted = deal_per_pass ? (n_dirty + deal_per_pass - 1u) / deal_per_pass : 0u;
