@@ -324,7 +324,8 @@ int rtmi_visible_points(rtmi_patches *, uint64_t m, const int32_t *ej, const dou
  * the counter-based generator documented in DESIGN.md (stream = seed, i, j, sample).
  * n = n_patches + 1 (the light is patch n-1, its row is zero) if light_center != NULL, else n_patches.
  * Writes rows [row0, row0+n_rows) of the n × n matrix as fp32: d_F[(r-row0)·ld + c].  Rows shard
- * across GPUs with no communication.
+ * across GPUs with no communication.  ld >= n, a multiple of 4 (16-byte rows); choose a multiple of 32 (rows that start on
+ * 128-byte lines): the sweeps that read the matrix back run 8 % faster on it (64 745 columns: 2.93 -> 2.69 ms per sweep).
  * Two kernels compute the same matrix bit for bit: one follows the two patches' paths through the hierarchy
  * (fast in rooms), one descends from the root (fast in clutter).  The first call on a patch set that covers at least 256 patch
  * rows of at least 1024 patches times both on its first rows (up to 1024) and keeps the faster for that patch set — that one call
