@@ -28,6 +28,7 @@
 // workgroup touches (its four groups' paths, the band's paths) are a few hundred KB and stay in its XCD's L2.
 #include "rtmi_rad_device.hpp"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -831,6 +832,8 @@ struct TableWalk {
 static int build_ff_tables(rtmi_patches *P, const char *who) {
 	std::lock_guard<std::mutex> lock(P->ff_mutex);
 	if (P->ff_ready) return 0;
+	const auto t_begin = std::chrono::steady_clock::now();
+	auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
 	const rtmi_scene *s = P->scene;
 	const uint32_t n = P->n;
 	TableWalk W;
@@ -854,10 +857,13 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	W.delta = 9.094947017729282e-13 * (1.0 + (double)s->dev.absmax); // 2^-40·(1 + |coord|max)
 	const char *planes = std::getenv("RTMI_FF_PLANES"); // "0": no plane flags (tests compare both settings)
 	W.flags_on = W.delta <= 1.25e-9 && !(planes && planes[0] == '0') && W.all_normals_geometric();
+	const double ms_read = ms_since();
 	W.node_box.resize(W.nodes.size());
 	if (W.flags_on) (void)W.bounds(s->dev.root_ref, 0u);
 	W.dfs.reserve(((size_t)n + 63) / 64 * 64);
+	W.chain.reserve((size_t)n * std::min<size_t>(s->info.max_depth, 24)); // (an estimate: a balanced tree's paths are log2 n long; no reallocation on the way for those)
 	W.walk(s->dev.root_ref, 0u, 0u);
+	const double ms_walk = ms_since();
 	if (W.bad || W.dfs.size() != n) return fail(std::string(who) + ": the hierarchy is not a binary tree over the patches with one triangle per leaf");
 	if (W.chain.size() > 0xffffffffull) return fail(std::string(who) + ": path table too large");
 	const uint32_t n_groups = (n + 63u) / 64u;
@@ -932,6 +938,7 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 		}
 		gconst[4 * (size_t)g + 2] = key;
 	}
+	const double ms_consts = ms_since();
 	void *d_chain = nullptr, *d_meta = nullptr, *d_gconst = nullptr;
 	uint32_t *d_dfs = nullptr;
 	bool ok = hipMalloc(&d_chain, W.chain.size() * sizeof(ChainEntry)) == hipSuccess && hipMalloc(&d_meta, (size_t)n * sizeof(PatchMeta)) == hipSuccess &&
@@ -953,6 +960,9 @@ static int build_ff_tables(rtmi_patches *P, const char *who) {
 	P->plane_delta = W.flags_on ? W.delta : -1.0;
 	P->graze_cos_j = P->graze_cos_i = graze_cos;
 	P->ff_ready = true;
+	if (env_uint("RTMI_VERBOSE", 0))
+		std::fprintf(stderr, "%s: path tables of %u patches: read back %.1f ms, walk %.1f ms, group constants %.1f ms, upload %.1f ms (%zu chain entries)\n", who, n,
+		             ms_read, ms_walk - ms_read, ms_consts - ms_walk, ms_since() - ms_consts, W.chain.size());
 	return 0;
 }
 
@@ -1017,6 +1027,7 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		return launch_check(who);
 	};
 	int kernel = 0;
+	uint32_t done_rows = 0; // leading rows of this call that the kernel choice below has already written
 	const char *mode = std::getenv("RTMI_FF_KERNEL");
 	if (mode && std::strcmp(mode, "flat") == 0) kernel = 2;
 	else if (mode && std::strcmp(mode, "path") == 0) kernel = 1;
@@ -1041,18 +1052,27 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		const bool capturing = hipStreamIsCapturing(st, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone;
 		if (kernel == 0 && !capturing && P->n >= 1024 && rows_p >= 256) {
 			const uint32_t cal = std::min(rows_p, 1024u);
-			// (the root traversal has one lane per entry and workgroups of even length: a quarter of the rows times it as
-			// well, and it is the slower kernel wherever the path walk serves at all — 66 ms of this call's 120 on the 64 K box)
-			const uint32_t cal_flat = std::max(256u, cal / 4u);
+			// (the root traversal has one lane per entry and workgroups of even length, and it is the slower kernel wherever the path
+			// walk serves at all: slices of at least 2^21 entries — 8 192 workgroups, four to five rounds of the device; slices of
+			// 2^20 made it look 1.8 times slower than it is — from both ends of the sample time it as well as the 256 rows it had
+			// until round 3, which were 17 ms of this call's 93 on the 64 K box.  64 K patches: 2 slices of 32 rows; 14 676: one of
+			// 143; below 8 192 patches: the 256 rows as before.)
+			const uint32_t slice = std::min(256u, std::max(16u, (uint32_t)(((1ull << 21) + P->n - 1u) / P->n)));
+			const uint32_t n_slices = std::max(1u, std::min(4u, 64u / slice)), cal_flat = slice * n_slices;
 			hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 			bool ok = hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess && hipEventCreate(&ev[2]) == hipSuccess;
 			float t_path = 0.f, t_flat = 0.f;
-			// (an untimed run first: after idle time the first long kernel runs at clocks that are still ramping up)
-			ok = ok && launch_path(row0, cal, d_F) == 0;
-			ok = ok && hipEventRecord(ev[0], st) == hipSuccess && launch_path(row0, cal, d_F) == 0 && hipEventRecord(ev[1], st) == hipSuccess &&
-			     launch_flat(row0, cal_flat, d_F) == 0 && hipEventRecord(ev[2], st) == hipSuccess && hipEventSynchronize(ev[2]) == hipSuccess &&
+			// (an untimed run first, a quarter of the sample: after idle time the first long kernel runs at clocks that are still ramping up)
+			ok = ok && launch_path(row0, cal / 4u, d_F) == 0;
+			ok = ok && hipEventRecord(ev[0], st) == hipSuccess && launch_path(row0, cal, d_F) == 0 && hipEventRecord(ev[1], st) == hipSuccess;
+			for (uint32_t k = 0; ok && k < n_slices; ++k) {
+				const uint32_t at = n_slices > 1u ? (uint32_t)((uint64_t)(cal - slice) * k / (n_slices - 1u)) : 0u;
+				ok = launch_flat(row0 + at, slice, d_F + (uint64_t)at * ld) == 0; // (the same bits the path walk just wrote there)
+			}
+			ok = ok && hipEventRecord(ev[2], st) == hipSuccess && hipEventSynchronize(ev[2]) == hipSuccess &&
 			     hipEventElapsedTime(&t_path, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&t_flat, ev[1], ev[2]) == hipSuccess;
 			t_flat *= (float)cal / (float)cal_flat;
+			done_rows = cal; // rows [row0, row0 + cal) hold the result already, whichever kernel is chosen: both write the same bits
 			for (hipEvent_t e : ev)
 				if (e) (void)hipEventDestroy(e);
 			if (!ok) return fail(std::string(who) + ": timing the two form-factor kernels failed: " + hipGetErrorString(hipGetLastError()));
@@ -1063,7 +1083,9 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 		}
 		if (kernel == 0) kernel = 1; // small patch sets and small first calls: the path walk, not remembered
 	}
-	if ((kernel == 2 ? launch_flat(row0, n_rows, d_F) : launch_path(row0, n_rows, d_F)) != 0) return -1;
+	if (done_rows < n_rows &&
+	    (kernel == 2 ? launch_flat(row0 + done_rows, n_rows - done_rows, d_F + (uint64_t)done_rows * ld) : launch_path(row0 + done_rows, n_rows - done_rows, d_F + (uint64_t)done_rows * ld)) != 0)
+		return -1;
 	if (light_center) {
 		hipLaunchKernelGGL(k_ff_light_column, dim3((n_rows + kBlock - 1) / kBlock), dim3(kBlock), s->stack_bytes_binary, st, s->dev, pdev(P),
 		                   light_center[0], light_center[1], light_center[2], light_samples, seed, flags, row0, n_rows, d_F, ld);
