@@ -170,7 +170,12 @@ struct RayF {
 __device__ __forceinline__ float safe_rcp(float d) {
 	const float tiny = 1e-20f;
 	if (fabsf(d) < tiny) d = (d < 0.f) ? -tiny : tiny;
+	// (v_rcp_f32 — 1 ulp, safe under the pad — instead of the ten-instruction IEEE division was measured: no difference, -DRTMI_FAST_RCP)
+#ifdef RTMI_FAST_RCP
+	return __builtin_amdgcn_rcpf(d);
+#else
 	return 1.0f / d;
+#endif
 }
 
 __device__ __forceinline__ RayF make_rayf(const SceneDev &S, double ox, double oy, double oz, double dx, double dy, double dz) {
