@@ -341,6 +341,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 	// zeros; tests compare.)
 	const uint32_t gkey = RTMI_FF_SAME_PLANE ? gconst.z : 0u;
 	const uint32_t *t_pkey = reinterpret_cast<const uint32_t *>(t_gconst + n_groups);
+	const unsigned long long m_flat = (planes_on != 0u && !(S.absmax > 1e4f)) ? ~0ull : 0ull; // the certain-hit test applies at all (see there)
 	// dealing samples over the wave (below): lane L holds sample deal_k of the deal_q-th pair of a pass
 	const uint32_t deal_per_pass = RTMI_FF_REGROUP && samples <= 64u ? 64u / samples : 0u;
 	const uint32_t deal_m16 = uniform_u32((65536u + samples - 1u) / samples); // L div S = (L·m16) >> 16 for L < 64, S <= 64 (L·(m16·S − 2^16) < 2^16)
@@ -444,6 +445,8 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 			// ---- the samples of the pair, in the reference's order (:309-330) --------------------------------------
 			uint64_t h0 = mix64(seed ^ (((uint64_t)i << 32) | jj));
 			uint32_t e_front_i = front_i, e_front_j = front_j, e_lca = lca; // of the pair the lane is evaluating
+			unsigned long long m_act = __ballot(pair && !(n_pass != 0u && dirty));  // lanes that evaluate a pair in this iteration
+			unsigned long long m_clean = __ballot((front_i | front_j) == 0u);        // ... whose pair kept no sibling in front of a plane
 			double ff = 0.0;
 			for (uint32_t t = 0; t < samples + n_pass; ++t) {
 				uint32_t k = t;
@@ -466,6 +469,8 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 					e_lca = x ? (uint32_t)(__ffs((int)x) - 1) : 0u;
 					h0 = mix64(seed ^ (((uint64_t)i << 32) | jj));
 					k = deal_k;
+					m_act = __ballot(act);
+					m_clean = __ballot((e_front_i | e_front_j) == 0u);
 				}
 				double add = 0.0; // what this sample adds to its pair's sum
 				do {
@@ -487,9 +492,13 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				const double c1 = dot(dir, ni);
 				const double c2 = -dot(dir, nj);
 				const D3 org = xi + (kEpsilon * dir);
-				const bool shoot = act & (c1 > 0.0) & (c2 > 0.0);
+				// (votes as ANDs of the votes on single comparisons: a vote on a comparison is the comparison's own lane mask, a vote on
+				// an AND of them costs two more vector instructions)
+				const bool pos1 = c1 > 0.0, pos2 = c2 > 0.0;
+				const bool shoot = act & pos1 & pos2;
+				const unsigned long long m_shoot = __ballot(pos1) & __ballot(pos2) & m_act;
 				FF_COUNT(0, 1);
-				if (__ballot(shoot) == 0ull) break;
+				if (m_shoot == 0ull) break;
 				FF_COUNT(13, 1); FF_COUNT_LANES(9, shoot);
 				// Triangle i lies 1e-5 BEHIND the origin along the ray (t = −1e-5 up to rounding of relative size 1e-15/c1): it
 				// cannot be hit unless the ray all but grazes it — then it is tested like any other, and so is everything
@@ -510,12 +519,12 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				// keeps |det| out of the ±1e-8 window (and is >= graze_cos_j); dist² > 1e-6 keeps t = dist − 1e-5 (error below
 				// 1e-3·sure_margin/c2 < 3.4e-4) positive.  Flat, geometric-normal patches only (planes_on, as for the flags).
 				{
-					const bool sure = (planes_on != 0u) & !graze_i & (c2 > sure_cos) & (bmin_j * c2 > sure_margin) & (dist2 > 1e-6) &
-					                  (e_front_i == 0u) & (e_front_j == 0u) & !(S.absmax > 1e4f); // (plain ANDs: no branch, no phi behind the vote)
+					const unsigned long long m_sure = __ballot(c1 > graze_cos_i) & __ballot(c2 > sure_cos) & __ballot(bmin_j * c2 > sure_margin) &
+					                                  __ballot(dist2 > 1e-6) & m_clean & m_flat;
 #ifdef RTMI_FF_TIMING_ALL_SURE // timing experiment only (wrong results wherever something is in the way): every sample takes the certain path
 					if (true) {
 #else
-					if (__ballot(shoot && !sure) == 0ull) {
+					if ((m_shoot & ~m_sure) == 0ull) {
 #endif
 						FF_COUNT(79, 1);
 						if (shoot) {

@@ -70,13 +70,19 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 // bmin: the smallest of the point's three barycentric weights (exact: u, v and w = 1 − u − v are multiples of 2^-32)
 __device__ __forceinline__ D3 sample_point_hb(const double *__restrict__ e, uint64_t h0, uint32_t k, uint32_t which, double &bmin) {
 	const uint64_t h = mix64(h0 ^ (((uint64_t)k << 32) | which));
-	uint32_t hi = (uint32_t)(h >> 32);
+	uint32_t hi = (uint32_t)(h >> 32), lo = (uint32_t)h;
+	// u = hi·2^-32, v = lo·2^-32.  The reflection `if (u + v > 1) { u = 1 − u; v = 1 − v; }` on the integers: u + v = (hi + lo)·2^-32
+	// exactly (33 bits), so u + v > 1 <=> hi + lo > 2^32 <=> the 32-bit sum wraps and is not 0; 1 − u = (2^32 − hi)·2^-32 exactly,
+	// and 2^32 − hi is the 32-bit 0 − hi (hi > 0 here).  The same u and v as the doubles give, bit for bit, two instructions fewer.
+	const uint32_t sum = hi + lo;
+	const bool reflect = (sum < hi) & (sum != 0u);
+	hi = reflect ? 0u - hi : hi;
+	lo = reflect ? 0u - lo : lo;
 	// (seen as a 64-bit integer with a zero upper half, the conversion becomes cvt(0)·2^32 + cvt(hi): an addition of 0.0 the
 	// compiler may not fold; behind this it is one v_cvt_f64_u32)
 	asm volatile("" : "+v"(hi));
-	double u = (double)hi * 0x1.0p-32;
-	double v = (double)(uint32_t)h * 0x1.0p-32;
-	if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
+	const double u = (double)hi * 0x1.0p-32;
+	const double v = (double)lo * 0x1.0p-32;
 	const double w = 1.0 - u - v;
 	// fmin() first canonicalises operands that come out of a select (v_max_f64 x, x — for signalling NaNs); none of the three
 	// can be a NaN, so the bare instruction gives the same value
