@@ -237,6 +237,7 @@ int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err, unsigned n_threads
 	out.nodes.clear();
 	out.build_of.clear();
 	out.leaf_pos.assign(bvh.nodes.size(), 0u);
+	out.cover.assign(bvh.nodes.size(), 0xffffffffu);
 	out.stack_need = 0;
 	if (bvh.nodes.empty()) return 0;
 	auto area = [&](int32_t i) {
@@ -312,6 +313,25 @@ int build_wide(const Bvh2 &bvh, Wide4 &out, std::string &err, unsigned n_threads
 		plan[it.out_id] = p;
 	}
 	if (next_tri != bvh.order.size()) { err = "internal error: the 4-wide layout lost triangles"; return -1; }
+#if RTMI_FF_WIDE_WALK
+	// 1b. where each binary node's subtree sits in the wide hierarchy: a wide node's own binary node is the whole of it; a node
+	// the collapse opened on the way (between a wide node's binary node and one of its children) is some of its children
+	if (plan.size() >= (1u << 27)) { err = "more than 2^27 4-wide nodes"; return -1; }
+	{
+		std::vector<int32_t> parent(bvh.nodes.size(), -1);
+		for (size_t i = 0; i < bvh.nodes.size(); ++i)
+			if (bvh.nodes[i].left >= 0) { parent[bvh.nodes[i].left] = (int32_t)i; parent[bvh.nodes[i].right] = (int32_t)i; }
+		for (size_t w = 0; w < plan.size(); ++w) {
+			const Plan &p = plan[w];
+			out.cover[p.build_id] = (uint32_t)w;
+			for (uint32_t k = 0; k < p.nk; ++k)
+				for (int32_t m = parent[p.kid[k]]; m >= 0 && (uint32_t)m != p.build_id; m = parent[m]) {
+					if (out.cover[m] == 0xffffffffu) out.cover[m] = (uint32_t)w;
+					out.cover[m] |= 1u << (27 + k);
+				}
+		}
+	}
+#endif
 	// 2. the node words (parallel): the node's grid and the children's boxes on it
 	out.nodes.resize(plan.size());
 	out.build_of.resize(plan.size());
@@ -460,6 +480,51 @@ uint64_t check_wide(const Bvh2 &bvh, const Wide4 &wide) {
 	}
 	for (uint64_t k = 0; k < n; ++k) bad += seen_pos[k] ? 0 : 1; // every triangle reachable
 	if (visited != wide.nodes.size()) ++bad;
+#if RTMI_FF_WIDE_WALK
+	// cover: the named children of the named wide node are descendants of the binary node, and hold as many triangles as it does
+	if (wide.cover.size() != bvh.nodes.size()) return bad + 1;
+	std::vector<int32_t> parent(bvh.nodes.size(), -1);
+	std::vector<uint32_t> leaves(bvh.nodes.size(), 0u);
+	{
+		std::vector<int32_t> order; // parents before children
+		order.reserve(bvh.nodes.size());
+		order.push_back(0);
+		for (size_t q = 0; q < order.size(); ++q) {
+			const BuildNode &x = bvh.nodes[order[q]];
+			if (x.left < 0) continue;
+			parent[x.left] = parent[x.right] = order[q];
+			order.push_back(x.left);
+			order.push_back(x.right);
+		}
+		for (size_t q = order.size(); q-- > 0;) {
+			const BuildNode &x = bvh.nodes[order[q]];
+			leaves[order[q]] = x.left < 0 ? 1u : leaves[x.left] + leaves[x.right];
+		}
+	}
+	for (size_t m = 0; m < bvh.nodes.size(); ++m) {
+		if (bvh.nodes[m].left < 0) { bad += wide.cover[m] == 0xffffffffu ? 0 : 1; continue; }
+		const uint32_t c = wide.cover[m], w = c & 0x7ffffffu, mask = ((c >> 27) & 15u) ? ((c >> 27) & 15u) : 15u;
+		if (c == 0xffffffffu || w >= wide.nodes.size()) { ++bad; continue; }
+		const WideNode &g = wide.nodes[w];
+		const uint32_t ni = (g.w[3] >> 24) & 15u, nk = g.w[3] >> 28;
+		uint32_t sum = 0;
+		for (uint32_t k = 0; k < nk; ++k) {
+			if (!((mask >> k) & 1u)) continue;
+			int32_t b = -1;
+			if (k < ni) b = g.w[10] + k < wide.build_of.size() ? (int32_t)wide.build_of[g.w[10] + k] : -1;
+			else {
+				const uint32_t pos = (~(g.w[11] - (k << 3))) >> 3;
+				b = pos < n ? leaf_at[pos] : -1;
+			}
+			if (b < 0) { ++bad; continue; }
+			sum += leaves[b];
+			int32_t a = b;
+			for (int up = 0; up < 4 && a >= 0 && (size_t)a != m; ++up) a = parent[a];
+			if (a < 0 || (size_t)a != m) ++bad; // (a child of the whole node's own binary node IS that node's descendant: m == build_of[w] ends the walk too)
+		}
+		if ((((c >> 27) & 15u) >> nk) != 0u || sum != leaves[m]) ++bad; // (no bit beyond the node's children; 0 = all of them)
+	}
+#endif
 	return bad;
 }
 

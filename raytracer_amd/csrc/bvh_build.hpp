@@ -36,10 +36,20 @@ Bvh2 build_bvh2(const double *xyz, uint64_t n, uint32_t max_leaf, uint32_t max_d
 //   w[4..9] lo.x, hi.x, lo.y, hi.y, lo.z, hi.z: one byte per child      w[10] index of inner child 0
 //   w[11]   ~(first << 3), first = position of the triangle of child 0 if it were a leaf: child k's leaf reference is w[11] − 8k
 struct WideNode { uint32_t w[12]; };
+// Experiment (profiles/ab_r03.md, not kept): the form-factor kernel's rays walk a sibling's subtree through the 4-wide nodes
+// instead of the binary ones.  1 builds Wide4::cover, carries it through the scene and the path tables, and switches the walk.
+#ifndef RTMI_FF_WIDE_WALK
+#define RTMI_FF_WIDE_WALK 0
+#endif
+
 struct Wide4 {
 	std::vector<WideNode> nodes;    // nodes[0] = root; empty when the binary root is a leaf
 	std::vector<uint32_t> leaf_pos; // per binary build node: position of a leaf's triangle in the device's triangle array
 	std::vector<uint32_t> build_of; // per wide node: the binary inner node it stands for
+	std::vector<uint32_t> cover;    // per binary build node: which part of the wide hierarchy holds exactly its subtree — the wide node
+	                                // (bits 0..26) and, for a binary node the collapse opened, those of that node's children (mask in
+	                                // bits 27..30; 0 = the whole node); 0xffffffff for leaves.  Who walks a binary node's subtree
+	                                // through the wide nodes starts there (the form-factor kernel's siblings).
 	uint32_t stack_need = 0;        // entries the deepest root-to-leaf path can leave on the traversal stack
 	uint32_t n_top = 0;             // nodes[0 .. n_top) are the root, its inner children and their inner children (<= 21)
 };

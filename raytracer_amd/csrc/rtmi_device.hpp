@@ -286,7 +286,7 @@ __device__ __forceinline__ void pair_fetch(const SceneDev &S, int cur, uint32_t 
 	c = odd ? r3 : x;  // even: the c(n0) its neighbour fetched
 }
 
-__device__ __forceinline__ int node_step_abc(const SceneDev &S, const RayW &r, float tbest, uint4 a, uint4 b, uint4 c, int &sp, int *stack);
+__device__ __forceinline__ int node_step_abc(const SceneDev &S, const RayW &r, float tbest, uint4 a, uint4 b, uint4 c, int &sp, int *stack, uint32_t allow = 15u);
 __device__ __forceinline__ int node_step(const SceneDev &S, const RayW &r, float tbest, int cur, int &sp, int *stack, const WNode *top = nullptr,
                                          uint32_t n_top = 0) {
 #ifdef RTMI_NODE_STRIDE // experiment: nodes at a stride of 64 B (none straddles a cache line), 48 B of each used
@@ -302,7 +302,9 @@ __device__ __forceinline__ int node_step(const SceneDev &S, const RayW &r, float
 	{ a = np->a; b = np->b; c = np->c; }
 	return node_step_abc(S, r, tbest, a, b, c, sp, stack);
 }
-__device__ __forceinline__ int node_step_abc(const SceneDev &S, const RayW &r, float tbest, uint4 a, uint4 b, uint4 c, int &sp, int *stack) {
+// allow: which of the node's children take part (bit K = child K; 15 = all, folded away by the compiler) — a walk that starts at a
+// binary node the collapse opened enters its wide node for SOME of the children only (Wide4::cover, node_step_cover)
+__device__ __forceinline__ int node_step_abc(const SceneDev &S, const RayW &r, float tbest, uint4 a, uint4 b, uint4 c, int &sp, int *stack, uint32_t allow) {
 	const float ax = ldexpf(r.ix, sbyte(a.w, 0)), ay = ldexpf(r.iy, sbyte(a.w, 1)), az = ldexpf(r.iz, sbyte(a.w, 2));
 	const float px = __uint_as_float(a.x), py = __uint_as_float(a.y), pz = __uint_as_float(a.z);
 	const float bnx = fmaf(px, r.ix, r.cnx), bny = fmaf(py, r.iy, r.cny), bnz = fmaf(pz, r.iz, r.cnz);
@@ -317,7 +319,7 @@ __device__ __forceinline__ int node_step_abc(const SceneDev &S, const RayW &r, f
 	{                                                                                                                         \
 		const float tn = fmaxf(fmaxf(fmaf(ubyte<K>(nxw), ax, bnx), fmaf(ubyte<K>(nyw), ay, bny)), fmaxf(fmaf(ubyte<K>(nzw), az, bnz), 0.0f)); \
 		const float tf = fminf(fminf(fmaf(ubyte<K>(fxw), ax, bfx), fmaf(ubyte<K>(fyw), ay, bfy)), fminf(fmaf(ubyte<K>(fzw), az, bfz), tbest)); \
-		key[K] = (tn <= tf && (K < 2 || n_child > K)) ? ((__float_as_uint(tn) & ~3u) | K) : 0xffffffffu;                       \
+		key[K] = (tn <= tf && (K < 2 || n_child > K) && ((allow >> K) & 1u)) ? ((__float_as_uint(tn) & ~3u) | K) : 0xffffffffu; \
 	}
 	RTMI_CHILD(0) RTMI_CHILD(1) RTMI_CHILD(2) RTMI_CHILD(3) // a node has at least two children (check_wide): no count test for 0 and 1
 #undef RTMI_CHILD
@@ -341,6 +343,15 @@ __device__ __forceinline__ int node_step_abc(const SceneDev &S, const RayW &r, f
 	if (key[2] != 0xffffffffu) { stack[sp * kBlock] = ref_of(key[2] & 3u); ++sp; }
 	if (key[1] != 0xffffffffu) { stack[sp * kBlock] = ref_of(key[1] & 3u); ++sp; }
 	return ref_of(key[0] & 3u);
+}
+
+// A node step from a reference that may name only some of a node's children: node index in bits 0..26, children in bits 27..30
+// (0 = all) — what Wide4::cover holds and what this step's own pushes are (plain indices).
+__device__ __forceinline__ int node_step_cover(const SceneDev &S, const RayW &r, float tbest, int cur, int &sp, int *stack) {
+	const uint32_t some = ((uint32_t)cur >> 27) & 15u;
+	const WNode *np = S.wnodes + ((uint32_t)cur & 0x7ffffffu);
+	const uint4 a = np->a, b = np->b, c = np->c;
+	return node_step_abc(S, r, tbest, a, b, c, sp, stack, some ? some : 15u);
 }
 
 // float >= x (x >= 0)

@@ -39,12 +39,12 @@
 namespace rtmi {
 
 // One sibling along a root-to-leaf path: its fp32 bounds (the quantised box of the binary node, which contains the
-// triangles' bounds) and its reference (inner node >= 0, leaf < 0 as in QNode).  32 B = two 16-byte loads.
+// triangles' bounds) and its reference (inner node >= 0, leaf < 0 as in QNode) in both hierarchies.  32 B = two 16-byte loads.
 struct __attribute__((aligned(16))) ChainEntry {
 	float lo[3];
-	int32_t ref;
+	int32_t ref;  // in the binary hierarchy (the beam walk)
 	float hi[3];
-	uint32_t level;
+	int32_t wide; // = ref; with -DRTMI_FF_WIDE_WALK=1 (experiment, not kept) where the same subtree sits in the 4-wide hierarchy (Wide4::cover)
 };
 // Per patch (original id): where its path's siblings start in the chain array, the path itself (bit L = went right at
 // level L), its length (< 32) with the position of its triangle in the leaf-ordered array (< kMaxFirst = 2^27) in one word,
@@ -160,10 +160,15 @@ __device__ __forceinline__ void patch_bounds(const double *v, float lo[3], float
 	}
 }
 
-// The ordinary stack traversal (binary nodes), started from whatever a lane holds: `cur` (a node, a leaf reference, or
+__device__ __forceinline__ int step_from(const SceneDev &S, const RayF &r, float tbest, int cur, int &sp, int *stack) { return node_step(S, r, tbest, cur, sp, stack); }
+__device__ __forceinline__ int step_from(const SceneDev &S, const RayW &r, float tbest, int cur, int &sp, int *stack) { return node_step_cover(S, r, tbest, cur, sp, stack); }
+
+// The ordinary stack traversal, started from whatever a lane holds: `cur` (a node, a leaf reference, or
 // kSentinel) and `sp` entries on its stack.  Closest hit with the tie rule; vote-scheduled like trace(): per iteration the
 // wave takes ONE node step or ONE triangle step.
-__device__ __forceinline__ void trace_from(const SceneDev &S, const RayF &rf, double ox, double oy, double oz, double dx, double dy, double dz,
+// RayW: through the 4-wide nodes, from references that may name some of a node's children (node_step_cover); RayF: the binary nodes.
+template <class Ray>
+__device__ __forceinline__ void trace_from(const SceneDev &S, const Ray &rf, double ox, double oy, double oz, double dx, double dy, double dz,
                                            double &best, uint32_t &pos, int cur, int sp, int *stack, uint32_t tag = 0u) {
 	(void)tag; // diagnostic builds: which kind of call the steps are counted under
 	float tbest = f32_above(best);
@@ -180,7 +185,7 @@ __device__ __forceinline__ void trace_from(const SceneDev &S, const RayF &rf, do
 		if (n_node + n_leaf == 0) break;
 		if (n_node >= n_leaf) {
 			FF_COUNT(6, 1); FF_COUNT(11, n_node); FF_COUNT(74 + tag, 1);
-			if (cur >= 0) cur = node_step(S, rf, tbest, cur, sp, stack);
+			if (cur >= 0) cur = step_from(S, rf, tbest, cur, sp, stack);
 		} else if (cur == kLeaf) {
 			FF_COUNT(7, 1); FF_COUNT(12, n_leaf); FF_COUNT(76 + tag, 1);
 			const GTri T = load_tri(S.tris + tk);
@@ -266,7 +271,7 @@ RTMI_TRAVERSAL_KERNEL void k_ff_light_column(SceneDev S, PatchesDev P, double cx
 // Workgroup = ONE group of 64 patches j (blockIdx.x); its four waves take four consecutive bands of rows i, so the group's
 // per-lane tables are fetched once per workgroup and shared through the L1.  Columns j < n_patches only; the light's row
 // (i == n_patches) is zero (:391-393), the diagonal too (:382).
-// stack: pend_cap + depth + 1 entries per lane — sibling subtrees waiting, and the traversal inside one of them.
+// stack: pend_cap + (the deeper hierarchy's path) + 1 entries per lane — sibling subtrees waiting, and the traversal inside one of them.
 // (The tables come as separate __restrict__ pointers: only then does the compiler know that the stores to F cannot change
 // them, and fetches everything that depends on i alone with scalar loads.)
 RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const double *__restrict__ p_verts, const double *__restrict__ p_normals,
@@ -578,20 +583,20 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 					FF_COUNT(1, 1);
 					const uint32_t L = (uint32_t)__builtin_ctz(m);
 					const float4 a = *reinterpret_cast<const float4 *>(chain_i + L), b = *(reinterpret_cast<const float4 *>(chain_i + L) + 1);
-					if (walk && ((s_i >> L) & 1u) && slab_box(a, b, rs, tb0)) { push(__float_as_int(a.w)); FF_COUNT(16 + L, 1); }
+					if (walk && ((s_i >> L) & 1u) && slab_box(a, b, rs, tb0)) { push(__float_as_int(RTMI_FF_WIDE_WALK ? b.w : a.w)); FF_COUNT(16 + L, 1); }
 				}
 				for (uint32_t m = um_j; m; m &= m - 1u) { // wave-uniform
 					FF_COUNT(2, 1);
 					const uint32_t L = (uint32_t)__builtin_ctz(m);
 					const float4 a = *reinterpret_cast<const float4 *>(chain_0 + L), b = *(reinterpret_cast<const float4 *>(chain_0 + L) + 1);
-					if (walk && ((s_j >> L) & 1u) && slab_box(a, b, rs, tb0)) { push(__float_as_int(a.w)); FF_COUNT(48 + L, 1); }
+					if (walk && ((s_j >> L) & 1u) && slab_box(a, b, rs, tb0)) { push(__float_as_int(RTMI_FF_WIDE_WALK ? b.w : a.w)); FF_COUNT(48 + L, 1); }
 				}
 				for (uint32_t m = walk ? own_j : 0u; __ballot(m != 0u) != 0ull; m &= m - 1u) { // per lane
 					FF_COUNT(3, 1);
 					if (m) {
 						const uint32_t L = (uint32_t)__builtin_ctz(m);
 						const float4 a = *reinterpret_cast<const float4 *>(chain_j + L), b = *(reinterpret_cast<const float4 *>(chain_j + L) + 1);
-						if (slab_box(a, b, rs, tb0)) { push(__float_as_int(a.w)); FF_COUNT(48 + L, 1); }
+						if (slab_box(a, b, rs, tb0)) { push(__float_as_int(RTMI_FF_WIDE_WALK ? b.w : a.w)); FF_COUNT(48 + L, 1); }
 					}
 				}
 				}
@@ -600,7 +605,11 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
 				if (__ballot(cur != kSentinel) != 0ull) {
 					FF_COUNT(5, 1); FF_COUNT(72, any_graze ? 1 : 0); FF_COUNT_LANES(73, walk && (graze_i || graze_j) && cur != kSentinel); FF_COUNT_LANES(78, cur != kSentinel);
+#if RTMI_FF_WIDE_WALK
+					const RayW rf = make_rayw(S, org.x, org.y, org.z, dir.x, dir.y, dir.z);
+#else
 					const RayF rf = make_rayf(S, org.x, org.y, org.z, dir.x, dir.y, dir.z);
+#endif
 					trace_from(S, rf, org.x, org.y, org.z, dir.x, dir.y, dir.z, best, pos, cur, sp, stack, any_graze ? 1u : 0u);
 				}
 				if (shoot && pos != RTMI_MISS) {
@@ -797,7 +806,13 @@ struct TableWalk {
 				e[c].hi[a] = f32_above_h(plane(w[c][a] >> 16, a));
 			}
 			e[c].ref = child[c];
-			e[c].level = depth;
+			e[c].wide = child[c];
+#if RTMI_FF_WIDE_WALK
+			if (child[c] >= 0) {
+				if ((size_t)child[c] >= s->wide_of_node.size() || s->wide_of_node[child[c]] == 0xffffffffu) { bad = true; return; }
+				e[c].wide = (int32_t)s->wide_of_node[child[c]];
+			}
+#endif
 		}
 		sib.push_back(e[1]); // walking into child 0, the other child is the sibling at this level
 		sib_box.push_back(flags_on ? box_of(child[1]) : Box3());
@@ -1028,8 +1043,11 @@ int rtmi_form_factors_dev(rtmi_patches *P, const double *light_center, uint32_t 
 #endif
 		// a lane's stack: up to pend_cap sibling subtrees waiting (more is rare: that ray starts over from the root) + the
 		// depth + 1 entries the traversal inside one of them can need
-		const uint32_t pend_cap = std::min(s->info.max_depth + 1u, std::max(1u, env_uint("RTMI_FF_PEND", 8)));
-		const uint32_t lds = (s->info.max_depth + 1u + pend_cap) * kBlock * (uint32_t)sizeof(int);
+		uint32_t pend_cap = std::min(s->info.max_depth + 1u, std::max(1u, env_uint("RTMI_FF_PEND", 8)));
+		const uint32_t walk_bytes = RTMI_FF_WIDE_WALK ? s->stack_bytes : (s->info.max_depth + 1u) * kBlock * (uint32_t)sizeof(int);
+		while (pend_cap > 1u && walk_bytes + pend_cap * kBlock * sizeof(int) > 64u * 1024u) --pend_cap; // (a workgroup's 64 KB: a very deep hierarchy leaves fewer waiting entries; rays with more start over from the root)
+		// (s->stack_bytes: the deeper of the two hierarchies' paths — the rays walk the 4-wide one, the beams the binary one)
+		const uint32_t lds = walk_bytes + pend_cap * kBlock * (uint32_t)sizeof(int);
 		hipLaunchKernelGGL(k_form_factors, grid, dim3(kBlock), lds, st, s->dev, (const double *)P->d_verts, (const double *)P->d_normals,
 		                   (const double *)P->d_area, P->n, static_cast<const ChainEntry *>(P->d_chain), static_cast<const PatchMeta *>(P->d_meta),
 		                   P->d_dfs, static_cast<const uint4 *>(P->d_gconst), samples, seed, first, count, band, margin, P->graze_cos_i, P->graze_cos_j, P->plane_delta >= 0.0 ? 1u : 0u, pend_cap, P->n_groups, out, ld);

@@ -31,6 +31,7 @@ struct rtmi_scene {
 	uint32_t n_objects; // 1 + the largest tri_object seen at creation (materials are looked up by it)
 	double *d_v1_orig; // n_tris × 3: triVert1 of every triangle in ORIGINAL order (hit points, object.cpp:23)
 	uint64_t xyz_hash; // of the vertex array the scene was built from (rtmi_patches_create must be handed the same one)
+	std::vector<uint32_t> wide_of_node; // per binary device node: rtmi::Wide4::cover of its subtree (the form-factor path tables start walks there)
 };
 
 namespace rtmi {

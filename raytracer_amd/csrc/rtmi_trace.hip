@@ -512,6 +512,10 @@ static rtmi_scene *scene_create(const double *xyz, const uint32_t *obj, uint64_t
 		while (!todo.empty()) {
 			Item it = todo.back();
 			todo.pop_back();
+#if RTMI_FF_WIDE_WALK
+			if (s->wide_of_node.size() <= (size_t)it.out_id) s->wide_of_node.resize((size_t)it.out_id + 1, 0xffffffffu);
+			s->wide_of_node[it.out_id] = wide.cover[it.build_id];
+#endif
 			const BuildNode &b = bvh.nodes[it.build_id];
 			const BuildNode &c0 = bvh.nodes[b.left], &c1 = bvh.nodes[b.right];
 			int32_t r0, r1;
