@@ -161,6 +161,12 @@ int rtmi_debug_check_hierarchy(const double *tri_xyz, uint64_t n_tris, uint64_t 
  * compiler's three plain IEEE divisions; the tests require the two outputs to be the same bits. */
 int rtmi_debug_div3_dev(const double *d_num3, const double *d_den, uint64_t n, double *d_shared3, double *d_plain3, void *stream);
 
+/* Test hook, no reference counterpart: n unit vectors vec3[3k..3k+2] / |vec3[3k..3k+2]| by the form-factor kernel's bare sequence
+ * (csrc/rtmi_device.hpp: unit_of_len2 — the compiler's square root and the three divisions without the range handling that does
+ * nothing for operands away from the ends of the exponent range; a wave runs it only when all its lanes are in that range) and by
+ * the plain root and divisions; the tests require the two outputs to be the same bits. */
+int rtmi_debug_unit_dev(const double *d_vec3, uint64_t n, double *d_fast3, double *d_plain3, void *stream);
+
 /* ---- wavefront: secondary rays generated on the device -----------------------------------------------
  * The batch producers between two ray-query calls, so that a frame's hit records never leave HBM:
  * d_rays[k] produced d_hits[k]; d_normals = n_tris × 3 doubles, the reference's triNormal per ORIGINAL triangle

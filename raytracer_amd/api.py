@@ -87,7 +87,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_
 SYMBOLS = [
     "rtmi_last_error", "rtmi_device_count", "rtmi_triangle_intersection", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_get_info", "rtmi_scene_check",
     "rtmi_closest_hit", "rtmi_closest_hit_dev", "rtmi_camera_setup", "rtmi_primary_closest_hit_dev", "rtmi_primary_closest_hit_samples_dev",
-    "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev", "rtmi_shadow_occlusion_dev", "rtmi_debug_check_hierarchy", "rtmi_debug_form_factor_kernel", "rtmi_debug_form_factor_planes", "rtmi_debug_div3_dev", "rtmi_radiosity_vertex_values",
+    "rtmi_primary_rays_dev", "rtmi_primary_work_dev", "rtmi_shadow_rays_dev", "rtmi_ao_rays_dev", "rtmi_ao_occlusion_dev", "rtmi_shadow_occlusion_dev", "rtmi_debug_check_hierarchy", "rtmi_debug_form_factor_kernel", "rtmi_debug_form_factor_planes", "rtmi_debug_div3_dev", "rtmi_debug_unit_dev", "rtmi_radiosity_vertex_values",
     "rtmi_occlusion_fraction_dev", "rtmi_any_hit", "rtmi_any_hit_dev", "rtmi_patches_create", "rtmi_patches_destroy",
     "rtmi_visible_points", "rtmi_form_factors_dev", "rtmi_jacobi_sweep_dev", "rtmi_radiosity_solve_dev", "rtmi_radiosity_solve_noalloc_dev",
     "rtmi_comm_unique_id", "rtmi_comm_create", "rtmi_comm_destroy", "rtmi_radiosity_solve_sharded_dev",
@@ -136,6 +136,7 @@ def _load():
     L.rtmi_debug_form_factor_planes.argtypes = [vp]
     L.rtmi_radiosity_vertex_values.argtypes = [vp, u32, vp, vp]
     L.rtmi_debug_div3_dev.argtypes = [vp, vp, u64, vp, vp, vp]
+    L.rtmi_debug_unit_dev.argtypes = [vp, u64, vp, vp, vp]
     L.rtmi_occlusion_fraction_dev.argtypes = [vp, u64, u32, vp, vp]
     L.rtmi_soft_shadow_rays_dev.argtypes = [vp, vp, vp, vp, u64, vp, u32, vp, vp]
     L.rtmi_soft_shadow_factor_dev.argtypes = [vp, vp, u64, u32, vp, vp]

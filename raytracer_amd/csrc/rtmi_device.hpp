@@ -952,6 +952,42 @@ __device__ __forceinline__ D3 div3(D3 a, double c) { return d3(a.x / c, a.y / c,
 #endif
 __device__ __forceinline__ D3 operator/(D3 a, double c) { return div3(a, c); }                            // vec3.h:46
 __device__ __forceinline__ double len2(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }              // vec3.h:14
+// a / sqrt(d2) with d2 = len2(a), bit for bit what the compiler's square root and div3 give — for the form-factor kernel's sample
+// loop, where the two are a fifth of the common path.  Both expansions carry range handling that acts only at the ends of the
+// exponent range: the root rescales operands below 2^-767 and passes 0 and inf through; a division's v_div_scale / v_div_fmas /
+// v_div_fixup rescale when an operand or the quotient comes near a denormal or the two exponents lie 768 apart, and patch up zeros,
+// infinities and NaNs.  When EVERY lane of the wave has 2^-600 <= d2 <= 2^600 and all three |components| >= 2^-300 (then the
+// length lies in 2^±300, the quotients in [2^-601, 1]: nothing is rescaled, nothing is special), the wave runs the bare sequences
+// — the same instructions on the same operands minus the ones that would do nothing: 24 instead of 43.  Otherwise the plain forms.
+// (tests/test_gpu_parity.py: test_unit_vector_fast_path_is_the_plain_root_and_division)
+__device__ __forceinline__ D3 unit_of_len2(D3 a, double d2) {
+#ifndef RTMI_PLAIN_UNIT
+	double m;
+	asm("v_min_f64 %0, |%1|, |%2|" : "=v"(m) : "v"(a.x), "v"(a.y));
+	asm("v_min_f64 %0, %1, |%2|" : "=v"(m) : "v"(m), "v"(a.z));
+	if ((__ballot(d2 >= 0x1.0p-600) & __ballot(d2 <= 0x1.0p600) & __ballot(m >= 0x1.0p-300)) == __ballot(true)) {
+		// the root (llvm's expansion without the scaling by 2^256 / 2^-128 and the class test)
+		const double y = __builtin_amdgcn_rsq(d2);
+		double g = d2 * y, h = y * 0.5;
+		const double r0 = __builtin_fma(-h, g, 0.5);
+		g = __builtin_fma(g, r0, g);
+		h = __builtin_fma(h, r0, h);
+		const double e0 = __builtin_fma(-g, g, d2);
+		g = __builtin_fma(e0, h, g);
+		const double e1 = __builtin_fma(-g, g, d2);
+		g = __builtin_fma(e1, h, g);
+		// three divisions by it (div3's shared form without the scalings and the fix-up)
+		double r = __builtin_amdgcn_rcp(g);
+		const double f0 = __builtin_fma(-g, r, 1.0);
+		r = __builtin_fma(r, f0, r);
+		const double f1 = __builtin_fma(-g, r, 1.0);
+		r = __builtin_fma(r, f1, r);
+		const double qx = a.x * r, qy = a.y * r, qz = a.z * r;
+		return d3(__builtin_fma(__builtin_fma(-g, qx, a.x), r, qx), __builtin_fma(__builtin_fma(-g, qy, a.y), r, qy), __builtin_fma(__builtin_fma(-g, qz, a.z), r, qz));
+	}
+#endif
+	return a / sqrt(d2);
+}
 __device__ __forceinline__ D3 unit(D3 a) {                                                              // vec3.h:98
 	const double d = len2(a);
 	return d > 0.0 ? a / sqrt(d) : d3(0, 0, 0);

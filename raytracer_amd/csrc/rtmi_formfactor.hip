@@ -491,7 +491,7 @@ RTMI_TRAVERSAL_KERNEL_W(RTMI_FF_WAVES) void k_form_factors(SceneDev S, const dou
 				// (The reference's Unit() returns 0 for a zero vector, vec3.h:98-101.  Here xj == xi gives 0/0: every component a
 				// NaN, both cosines NaNs, `shoot` false — what the zero vector gives (cosines ±0), without the branch around the
 				// root and the division.  A NaN direction is never used: everything below is under `shoot` or one of its subsets.)
-				const D3 dir = vec / sqrt(dist2);
+				const D3 dir = unit_of_len2(vec, dist2);
 				// A sample adds to the sum only if delF > 0, i.e. both cosines are positive (:320-324) — whatever the
 				// visibility ray says.  So the ray is shot only for those samples.
 				const double c1 = dot(dir, ni);

@@ -910,12 +910,34 @@ extern "C" int rtmi_debug_tail_read(unsigned long long *host_out) { // diagnosti
 	return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rtmi::g_tail_diag), sizeof(unsigned long long) * 5 * 8192) == hipSuccess ? 0 : -1;
 }
 #endif
+__global__ void k_debug_unit(const double *__restrict__ vec3, uint64_t n, double *__restrict__ fast3, double *__restrict__ plain3) {
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool in = k < n; // (every lane runs the wave-level vote of unit_of_len2)
+	const D3 a = in ? d3(vec3[3 * k], vec3[3 * k + 1], vec3[3 * k + 2]) : d3(1.0, 2.0, 3.0);
+	const double d2 = len2(a);
+	const D3 q = unit_of_len2(a, d2);
+	const double s = sqrt(d2);
+	if (in) {
+		fast3[3 * k] = q.x; fast3[3 * k + 1] = q.y; fast3[3 * k + 2] = q.z;
+		plain3[3 * k] = a.x / s; plain3[3 * k + 1] = a.y / s; plain3[3 * k + 2] = a.z / s;
+	}
+}
+
 int rtmi_debug_div3_dev(const double *d_num3, const double *d_den, uint64_t n, double *d_shared3, double *d_plain3, void *stream) {
 	const char *who = "rtmi_debug_div3_dev";
 	if (n == 0) return 0;
 	if (!d_num3 || !d_den || !d_shared3 || !d_plain3) return fail(std::string(who) + ": NULL argument");
 	if ((n + 255) / 256 > 0x7fffffffull) return fail(std::string(who) + ": too many elements");
 	hipLaunchKernelGGL(k_debug_div3, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_num3, d_den, n, d_shared3, d_plain3);
+	return launch_check(who);
+}
+
+int rtmi_debug_unit_dev(const double *d_vec3, uint64_t n, double *d_fast3, double *d_plain3, void *stream) {
+	const char *who = "rtmi_debug_unit_dev";
+	if (!d_vec3 || !d_fast3 || !d_plain3) return fail(std::string(who) + ": NULL argument");
+	if (n == 0) return 0;
+	if ((n + 255) / 256 > 0x7fffffffull) return fail(std::string(who) + ": too many elements");
+	hipLaunchKernelGGL(k_debug_unit, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_vec3, n, d_fast3, d_plain3);
 	return launch_check(who);
 }
 

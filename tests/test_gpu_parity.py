@@ -514,6 +514,46 @@ def test_shared_reciprocal_division_is_the_plain_division(rt):
             assert np.array_equal(ga.view(np.uint64)[~nan], want.view(np.uint64)[~nan])      # ... and so is the shared form
 
 
+def test_unit_vector_fast_path_is_the_plain_root_and_division(rt):
+    """csrc/rtmi_device.hpp unit_of_len2 (the direction of every form-factor sample: a / sqrt(a·a)) runs the compiler's square
+    root and the three divisions WITHOUT their range handling when every lane of the wave is far from the ends of the exponent
+    range, and the plain forms otherwise.  Same bits as the plain forms and as the host's IEEE root and division: on waves
+    that are all in range (ordinary magnitudes: the bare sequence runs), on waves at and across the guard's bounds, on the
+    whole exponent range, zeros, infinities and NaNs (the plain forms run)."""
+    import torch
+    rng = np.random.default_rng(23)
+    n = 1 << 21
+
+    def wide(k):
+        bits = rng.integers(0, 1 << 63, size=k, dtype=np.uint64) | (rng.integers(0, 2, size=k, dtype=np.uint64) << np.uint64(63))
+        return bits.view(np.float64)
+
+    sets = []
+    with np.errstate(all="ignore"):
+        sets.append(rng.normal(size=(n, 3)) * 10.0 ** rng.integers(-3, 4, size=(n, 1)))                                   # what the kernel sees
+        sets.append(rng.normal(size=(n, 3)) * 2.0 ** rng.integers(-40, 41, size=(n, 3)).astype(np.float64))              # components far apart
+        for e in (-302, -300, -298, 298, 300, 302, -151, 151):                                                             # around the guard's bounds
+            sets.append((1.0 + rng.random(size=(n // 8, 3))) * rng.choice([-1.0, 1.0], size=(n // 8, 3)) * 2.0 ** e)
+        v = rng.normal(size=(n // 8, 3)); v[:, 1] *= 2.0 ** -310; sets.append(v)                                          # one component below the bound
+        v = rng.normal(size=(n // 8, 3)); v[rng.integers(0, len(v), 5000), rng.integers(0, 3, 5000)] = 0.0; sets.append(v)  # zeros among ordinary lanes
+        sets.append(wide(3 * n).reshape(n, 3))                                                                             # anything
+        specials = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 1e-200, 1e200, 3.0, 1e-5])
+        sets.append(np.array(np.meshgrid(specials, specials, specials, indexing="ij")).reshape(3, -1).T.copy())
+        for vec in sets:
+            d = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64)).cuda()
+            a, b = torch.zeros_like(d), torch.zeros_like(d)
+            rc = rt.lib.rtmi_debug_unit_dev(d.data_ptr(), len(vec), a.data_ptr(), b.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rt.lib.rtmi_last_error().decode()
+            torch.cuda.synchronize()
+            ga, gb = a.cpu().numpy(), b.cpu().numpy()
+            d2 = vec[:, 0] * vec[:, 0] + vec[:, 1] * vec[:, 1] + vec[:, 2] * vec[:, 2]      # vec3.h:14, left to right
+            want = vec / np.sqrt(d2)[:, None]
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(gb), nan) and np.array_equal(np.isnan(ga), nan)
+            assert np.array_equal(gb.view(np.uint64)[~nan], want.view(np.uint64)[~nan])      # the compiler's root and division are IEEE
+            assert np.array_equal(ga.view(np.uint64)[~nan], want.view(np.uint64)[~nan])      # ... and the bare sequence gives the same bits
+
+
 def test_patches_must_be_the_scenes_triangles(rt):
     from raytracer_amd import workloads
     v = workloads.soup(50, seed=2, edge=0.3)
