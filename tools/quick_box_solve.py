@@ -7,7 +7,7 @@ import raytracer_amd as rt
 from raytracer_amd import workloads
 from raytracer_amd.api import rtmi_solve_stats
 torch.cuda.set_device(0)
-verts, normals, light = workloads.closed_box(int(sys.argv[1]) if len(sys.argv) > 1 else 74)
+verts, normals, light = workloads.closed_box(int(sys.argv[1]) if len(sys.argv) > 1 else 74, hole=0.3)   # the bench's box (a light inside a closed box lights nothing)
 box = rt.Scene(verts)
 rad = rt.Radiosity(box, normals, light)
 rad.findFormFactor(samples=10, light_samples=30, seed=1)
