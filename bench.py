@@ -426,7 +426,7 @@ def main():
                 try:
                     tj = json.load(open(tr)).get("k_form_factors", {})
                     for key in ("hbm_bytes_per_entry_fetch", "hbm_bytes_per_entry_write", "l2_hit_rate", "valu_issue_utilisation",
-                                "valu_instructions_per_pair_sample", "scratch_bytes", "vgprs"):
+                                "valu_instructions_per_lane_sample", "scratch_bytes", "vgprs"):
                         if key in tj:
                             roofline_formfactor[key] = tj[key]
                     if "hbm_bytes_per_launch" in tj and tj.get("rows_per_launch"):   # per launch of THIS size: the stored bytes scale with the rows
