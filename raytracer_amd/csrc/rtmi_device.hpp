@@ -990,7 +990,11 @@ __device__ __forceinline__ D3 unit_of_len2(D3 a, double d2) {
 }
 __device__ __forceinline__ D3 unit(D3 a) {                                                              // vec3.h:98
 	const double d = len2(a);
+#ifdef RTMI_UNIT_FAST // experiment (profiles/ab_r03.md): the bare root and divisions for every Unit() of the kernels
+	return d > 0.0 ? unit_of_len2(a, d) : d3(0, 0, 0);
+#else
 	return d > 0.0 ? a / sqrt(d) : d3(0, 0, 0);
+#endif
 }
 
 
