@@ -438,6 +438,18 @@ def test_form_factors_on_the_references_meshes(rt, oracle, monkeypatch, stem, ro
     F_auto = rad.findFormFactor(samples=10, seed=5, row0=row0, n_rows=384).cpu().numpy()[:, :n]
     assert rt.lib.rtmi_debug_form_factor_kernel(rad.handle) == 2
     assert np.array_equal(F_auto.view(np.uint32), F_path.view(np.uint32))
+    # a first call LONGER than the sample the choice is made on (1024 rows): the sample's rows are kept as written — by the path
+    # walk, with slices of them written again by the root traversal — and only the rest is launched, with the kernel chosen
+    if stem == "real_buddha":
+        rad2 = rt.Radiosity(scene, normals, None)
+        F_long = rad2.findFormFactor(samples=10, seed=5, row0=row0 - 900, n_rows=1300).cpu().numpy()[:, :n]
+        assert rt.lib.rtmi_debug_form_factor_kernel(rad2.handle) == 2
+        assert np.array_equal(F_long[900:1284].view(np.uint32), F_path.view(np.uint32))
+        monkeypatch.setenv("RTMI_FF_KERNEL", "flat")
+        F_long_flat = rad2.findFormFactor(samples=10, seed=5, row0=row0 - 900, n_rows=1300).cpu().numpy()[:, :n]
+        monkeypatch.delenv("RTMI_FF_KERNEL", raising=False)
+        assert np.array_equal(F_long.view(np.uint32), F_long_flat.view(np.uint32))
+        rad2.close()
 
 
 def test_form_factors_inside_a_graph_capture(rt):
