@@ -302,6 +302,30 @@ __device__ __forceinline__ int node_step(const SceneDev &S, const RayW &r, float
 	{ a = np->a; b = np->b; c = np->c; }
 	return node_step_abc(S, r, tbest, a, b, c, sp, stack);
 }
+// Experiment (RTMI_DRAIN_PREFETCH, profiles/ab_r03.md): once the launch's queue is dry a wave's time is its rays' chains of dependent
+// node fetches (≈ 2 µs per round of three steps, most of it waiting for L2).  A node's inner children lie next to each other
+// (c.z + k, 48 B each), so as soon as a node's words are in, the step asks for their lines with one or two loads nobody waits for;
+// the slab arithmetic runs meanwhile and the next step's own fetch finds the lines in L1.  gfx950 has no vector prefetch
+// instruction, and an ordinary load into a register nobody waits for may land after the compiler has given that register to
+// something else; so these are loads that write to LDS (global_load_lds_dword: 64 dwords at M0, a landing strip per wave that
+// nothing reads) — no register is involved, and the compiler's own waits only become more conservative.
+#ifndef RTMI_DRAIN_PREFETCH
+#define RTMI_DRAIN_PREFETCH 0
+#endif
+__device__ __forceinline__ int node_step_prefetching(const SceneDev &S, const RayW &r, float tbest, int cur, int &sp, int *stack, bool dry, uint32_t land) {
+	const WNode *np = S.wnodes + cur;
+	const uint4 a = np->a, b = np->b, c = np->c;
+	if (dry) { // wave-uniform
+		const uint32_t n_inner = (a.w >> 24) & 0xfu;
+		const char *kids = reinterpret_cast<const char *>(S.wnodes + c.z);
+		// (no instruction offset: it would move the landing address in LDS as well — the strip of the workgroup's last wave then
+		// reached into the traversal stacks behind it, and a launch faulted)
+		if (n_inner > 0u) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(kids), "s"(land) : "m0", "memory");
+		if (n_inner > 2u) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(kids + 128), "s"(land) : "m0", "memory"); // (bytes 128.. exist: three children are 144)
+	}
+	return node_step_abc(S, r, tbest, a, b, c, sp, stack);
+}
+
 // allow: which of the node's children take part (bit K = child K; 15 = all, folded away by the compiler) — a walk that starts at a
 // binary node the collapse opened enters its wide node for SOME of the children only (Wide4::cover, node_step_cover)
 __device__ __forceinline__ int node_step_abc(const SceneDev &S, const RayW &r, float tbest, uint4 a, uint4 b, uint4 c, int &sp, int *stack, uint32_t allow) {
@@ -523,6 +547,10 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 	float tbest = 0.f;
 	int sp = 0, cur = kSentinel;
 	uint32_t item = 0, tk = 0, tend = 0; // [tk, tend): triangles of the leaf this lane is working through (cur == kLeaf)
+#if RTMI_DRAIN_PREFETCH
+	__shared__ uint32_t pf_strip[kBlock]; // the landing strip of the drain's prefetch loads: 64 dwords per wave, never read
+	const uint32_t pf_land = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(pf_strip + (threadIdx.x & ~63u)));
+#endif
 	bool have = false; // this lane holds a ray (in flight, or finished and not yet emitted)
 	bool more = true;  // items are left for this wave: in its own range or in the launch's queue (wave-uniform)
 	bool global_more = true;
@@ -867,7 +895,11 @@ __device__ __forceinline__ void trace_queue(const SceneDev &S, int *stack, int *
 #else
 				if (cur >= 0) {
 					if (COUNT) { ++w->nodes; w->node_slots += wave_slots(); }
+#if RTMI_DRAIN_PREFETCH
+					cur = node_step_prefetching(S, r, tbest, cur, sp, stack, !more, pf_land);
+#else
 					cur = node_step(S, r, tbest, cur, sp, stack, top, n_top);
+#endif
 				}
 #endif
 			}
